@@ -1,0 +1,402 @@
+#!/usr/bin/env python3
+"""
+tests/golden/make_golden.py -- regenerates tests/golden/*.npz by running the REFERENCE itself.
+
+Run only in the build container, where /root/reference is mounted (it does not exist on
+the GPU box; nothing under tests/ reads it at test time):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference package ``src.svd_hybrid`` cannot be imported normally here (its __init__
+pulls torchvision/open_clip), so empty package modules are pre-registered and
+only the hot-path submodules are imported.  The fixtures are DATA:
+seeded inputs and the reference's outputs for them.  No reference source is stored.
+
+Fixture families (all .npz, loadable with allow_pickle=False):
+  rtvq_*.npz      quantizer: rtvq.py asymmetric/multistage functions and RTVQQuantizer
+  rtvq_large.npz  config #1: RTVQQuantizer(4,2) on a 768x768 tensor (seeded; checksums)
+  basis_*.npz     construct_basis -> .half() -> compress_single_task -> dequantize ->
+                  reconstruct_from_coefficients (the four-call parity chain)
+  config1.npz     N=2, one [768,768], center False/True (the F4 NaN case recorded as such)
+  masks.npz       combine_masks / apply_mask_to_tensor / get_unmasked_portion /
+                  reconstruct_from_masked / construct_masked_basis(include_noise)
+  pipeline.npz    cli.py Step 4 + Step 5 loop bodies over 3 layers x 4 tasks
+                  (construct_masked_basis + compress_all_parameters), dict layout + numbers
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+for _name, _path in (("src", REF + "/src"), ("src.svd_hybrid", REF + "/src/svd_hybrid")):
+    _m = types.ModuleType(_name)
+    _m.__path__ = [_path]
+    sys.modules[_name] = _m
+
+from src.svd_hybrid import rtvq as ref_rtvq                      # noqa: E402
+from src.svd_hybrid import basis as ref_basis                    # noqa: E402
+from src.svd_hybrid import compress as ref_compress              # noqa: E402
+from src.svd_hybrid import merge as ref_merge                    # noqa: E402
+from src.svd_hybrid import mask_loader as ref_masks              # noqa: E402
+import quantization_utils as ref_qutils                          # noqa: E402
+
+sys.path.insert(0, ROOT)
+from oracle.svd_hybrid_oracle import synthetic_deltas            # noqa: E402  (input generator only)
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+def payload_arrays(prefix, qobj, out):
+    """Flatten RTVQQuantizer.quantize output into arrays under ``prefix``."""
+    p = qobj["payloads"]
+    out[prefix + "n_payloads"] = np.int64(len(p))
+    if p:
+        out[prefix + "codes"] = np.stack([x["quantized"].numpy() for x in p])
+        out[prefix + "scale"] = np.array([x["scale"].item() for x in p], dtype=np.float32)
+        out[prefix + "zero_point"] = np.array([x["zero_point"].item() for x in p], dtype=np.float32)
+        out[prefix + "residual_norm"] = np.array([x["residual_norm"] for x in p], dtype=np.float64)
+        assert [x["stage"] for x in p] == list(range(len(p)))
+        assert all(x["quantized"].dtype == torch.uint8 for x in p)
+        assert all(x["scale"].ndim == 0 and x["zero_point"].ndim == 0 for x in p)
+
+
+# ------------------------------------------------------------------------------- quantizer
+def gen_rtvq():
+    cases = {}
+    g = torch.Generator().manual_seed(1234)
+    inputs = {
+        "n7": torch.randn(7, generator=g),
+        "n19": torch.randn(19, generator=g) * 3.0 + 1.0,
+        "n2": torch.tensor([-0.25, 0.75]),
+        "n100": torch.randn(100, generator=g),
+        "n4096": torch.randn(4096, generator=g) * 0.01,
+        "ramp5": torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0]),          # reference tests/test_rtvq.py:35
+        "ties": torch.tensor([0.0, 0.5, 1.5, 2.5, 3.5, 7.5, 15.0]),  # half-way cases at 4 bits
+        "one": torch.tensor([0.5]),                                 # F4: scale = inf
+        "const": torch.ones(5) * 3.14,                              # F4
+        "zeros": torch.zeros(3),                                    # F4
+        "hasnan": torch.tensor([1.0, float("nan"), -2.0, 0.5]),
+    }
+    for name, x in inputs.items():
+        cases[f"{name}__x"] = x.numpy()
+        for bits, stages in ((4, 2), (4, 4), (8, 2), (2, 2), (2, 3), (1, 2)):
+            tag = f"{name}__b{bits}s{stages}__"
+            quant = ref_rtvq.RTVQQuantizer(num_bits=bits, num_stages=stages)
+            obj = quant.quantize(x)
+            payload_arrays(tag, obj, cases)
+            cases[tag + "deq"] = quant.dequantize(obj).numpy()
+            assert obj["num_bits"] == bits and obj["num_stages"] == stages
+            assert tuple(obj["original_shape"]) == tuple(x.shape)
+            assert obj["original_dtype"] == "torch.float32"
+        # single-stage function + the quantization_utils copy named by north_star
+        for bits in (8, 4, 2):
+            q, sc, zp = ref_rtvq.asymmetric_quantization(x, bits)
+            q2, sc2, zp2 = ref_qutils.asymmetric_quantization(x, bits)
+            assert torch.equal(q, q2)
+            tag = f"{name}__asym{bits}__"
+            cases[tag + "q"] = q.numpy()
+            cases[tag + "scale"] = np.float32(sc.item())
+            cases[tag + "zero_point"] = np.float32(zp.item())
+            cases[tag + "deq"] = ref_rtvq.asymmetric_dequantization(q, sc, zp).numpy()
+            d2 = ref_qutils.dequantize_asymmetric(q2, sc2, zp2).numpy()
+            assert np.array_equal(cases[tag + "deq"], d2, equal_nan=True)
+    empty = ref_rtvq.RTVQQuantizer(4, 2).quantize(torch.tensor([]))
+    assert empty["payloads"] == []
+    cases["empty__deq_numel"] = np.int64(ref_rtvq.RTVQQuantizer(4, 2).dequantize(empty).numel())
+    cases["names"] = np.array(list(inputs.keys()))
+    save("rtvq_cases.npz", **cases)
+
+
+def gen_rtvq_large():
+    """Config #1: RTVQQuantizer(4,2) directly on the 589,824-element tensor."""
+    torch.manual_seed(0)
+    x = 0.01 * torch.randn(768, 768)
+    out = {"seed": np.int64(0), "x_sum": np.float64(x.double().sum().item()),
+           "x_first8": x.flatten()[:8].numpy()}
+    for bits, stages in ((4, 2), (8, 2), (2, 4)):
+        quant = ref_rtvq.RTVQQuantizer(bits, stages)
+        obj = quant.quantize(x)
+        tag = f"b{bits}s{stages}__"
+        p = obj["payloads"]
+        out[tag + "scale"] = np.array([t["scale"].item() for t in p], dtype=np.float32)
+        out[tag + "zero_point"] = np.array([t["zero_point"].item() for t in p], dtype=np.float32)
+        out[tag + "residual_norm"] = np.array([t["residual_norm"] for t in p], dtype=np.float64)
+        out[tag + "hist"] = np.stack([np.bincount(t["quantized"].numpy().ravel(), minlength=256)
+                                      for t in p])
+        w = (np.arange(x.numel(), dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+        out[tag + "weighted_sum"] = np.array(
+            [int((t["quantized"].numpy().ravel().astype(np.uint64) * w).sum()) for t in p],
+            dtype=np.uint64)
+        out[tag + "codes_head"] = np.stack([t["quantized"].numpy().ravel()[:64] for t in p])
+        deq = quant.dequantize(obj)
+        assert deq.shape == x.shape
+        out[tag + "deq_head"] = deq.flatten()[:64].numpy()
+        out[tag + "rel_err"] = np.float64(((x - deq).norm() / x.norm()).item())
+    save("rtvq_large.npz", **out)
+
+
+# ------------------------------------------------------------------------------- basis chain
+def basis_chain(deltas, thr, max_rank, center, fp16, bits, stages, store_inputs=True, store_full=True):
+    N = len(deltas)
+    b = ref_basis.construct_basis(deltas, energy_threshold=thr, max_rank=max_rank, center=center,
+                                  device="cpu", verbose=False)
+    out = {
+        "N": np.int64(N), "D": np.int64(b["D"]), "thr": np.float64(thr),
+        "max_rank": np.int64(-1 if max_rank is None else max_rank), "center": np.bool_(center),
+        "fp16": np.bool_(fp16), "bits": np.int64(bits), "stages": np.int64(stages),
+        "S": b["singular_values"].numpy(), "k": np.int64(b["k"]),
+        "energy_retained": np.float64(b["energy_retained"]),
+    }
+    assert b["N"] == N
+    if store_inputs:
+        out["deltas"] = torch.stack(deltas).numpy()
+    U_high, U_low = b["U_high"], b["U_low"]
+    assert U_high.is_contiguous() and U_low.is_contiguous()
+    assert U_high.shape == (b["D"], b["k"]) and U_low.shape == (b["D"], N - b["k"])
+    if center:
+        assert b["mean"].shape == (b["D"], 1)
+        m = b["mean"].squeeze(1)
+        if store_full or b["D"] <= 65536:
+            out["mean"] = m.numpy()
+        out["mean_sum"] = np.float64(m.double().sum().item())
+        out["mean_head"] = m[:64].numpy()
+    else:
+        assert b["mean"] is None
+    if fp16:                                                   # cli.py:354-361
+        U_high, U_low = U_high.half(), U_low.half()
+    if store_full:
+        out["U_high"] = U_high.numpy()
+        out["U_low"] = U_low.numpy()
+    quant = ref_rtvq.RTVQQuantizer(bits, stages)
+    c_high_all, c_low_all, c16_all, deq_all, recon_all = [], [], [], [], []
+    for t, d in enumerate(deltas):
+        d_c = d if b["mean"] is None else d - b["mean"].squeeze()
+        ch, cl = ref_compress.project_to_basis(d_c, U_high, U_low)
+        art = ref_compress.compress_single_task(d, U_high, U_low, quant, "cpu", mean=b["mean"])
+        assert set(art.keys()) == {"c_high_fp16", "c_low_quant"}
+        assert art["c_high_fp16"].dtype == torch.float16
+        payload_arrays(f"t{t}__", art["c_low_quant"], out)
+        cl_hat = quant.dequantize(art["c_low_quant"])
+        rec = ref_merge.reconstruct_from_coefficients(art["c_high_fp16"].float(), cl_hat.float(),
+                                                      U_high, U_low, "cpu", mean=b["mean"])
+        c_high_all.append(ch.numpy()); c_low_all.append(cl.numpy())
+        c16_all.append(art["c_high_fp16"].numpy()); deq_all.append(cl_hat.numpy().reshape(-1))
+        recon_all.append(rec.numpy())
+    out["c_high"] = np.stack(c_high_all)
+    out["c_low"] = np.stack(c_low_all)
+    out["c_high_fp16"] = np.stack(c16_all)
+    out["c_low_deq"] = np.stack(deq_all)
+    recon = np.stack(recon_all)
+    if store_full:
+        out["recon"] = recon
+    orig = torch.stack(deltas).numpy()
+    out["recon_rel_err"] = np.linalg.norm(recon - orig, axis=1) / np.linalg.norm(orig, axis=1)
+    out["recon_sq_sum"] = (recon.astype(np.float64) ** 2).sum(axis=1)
+    out["recon_head"] = recon[:, :64].copy()
+    return out
+
+
+def gen_basis():
+    specs = [
+        # name,            D,     N,  seed, thr,  max_rank, center, fp16, bits, stages, full
+        ("basis_d768_n8",   768,   8,  11,   0.90, None,     True,   True, 4,    2,      True),
+        ("basis_d768_n3",   768,   3,  12,   0.90, None,     True,   True, 4,    2,      True),
+        ("basis_d768_n20",  768,   20, 13,   0.90, None,     True,   True, 8,    2,      True),
+        ("basis_d768_n20b", 768,   20, 13,   0.95, 64,       True,   True, 2,    2,      True),
+        ("basis_d4096_n8",  4096,  8,  14,   0.90, None,     True,   True, 4,    4,      True),
+        ("basis_d4096_n8_nocenter", 4096, 8, 14, 0.90, None, False,  True, 4,    2,      True),
+        ("basis_d4096_n8_fp32",     4096, 8, 14, 0.95, 64,   True,   False, 4,   2,      True),
+        ("basis_d1000_n5",  1000,  5,  15,   0.50, None,     True,   True, 4,    2,      True),
+        ("basis_d999_n12",  999,   12, 16,   0.99, 4,        True,   True, 4,    2,      True),
+        ("basis_d65536_n8", 65536, 8,  17,   0.90, None,     True,   True, 4,    2,      False),
+    ]
+    for name, D, N, seed, thr, mr, center, fp16, bits, stages, full in specs:
+        deltas = synthetic_deltas(D, N, seed)
+        out = basis_chain(deltas, thr, mr, center, fp16, bits, stages,
+                          store_inputs=full, store_full=full)
+        out["seed"] = np.int64(seed)
+        out["delta_sum"] = np.float64(torch.stack(deltas).double().sum().item())
+        save(name + ".npz", **out)
+
+
+def gen_config1():
+    """BASELINE.json configs[0]: 2 synthetic tasks, single 768x768 linear, 2-stage 4-bit."""
+    torch.manual_seed(0)
+    deltas = [0.01 * torch.randn(768 * 768) for _ in range(2)]
+    out = {"delta_sum": np.float64(torch.stack(deltas).double().sum().item())}
+    for center in (False, True):
+        tag = "center__" if center else "nocenter__"
+        r = basis_chain(deltas, 0.9, None, center, True, 4, 2, store_inputs=False, store_full=False)
+        for key, val in r.items():
+            out[tag + key] = val
+    save("config1.npz", **out)
+
+
+# ------------------------------------------------------------------------------- masks
+def gen_masks():
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    shape = (40, 50)
+    N = 5
+    masks = [torch.rand(shape, generator=g) > 0.7 for _ in range(N)]
+    deltas = [d.view(shape) for d in synthetic_deltas(shape[0] * shape[1], N, 21)]
+    out["masks"] = torch.stack(masks).numpy()
+    out["deltas"] = torch.stack(deltas).numpy()
+    task_masks = {f"t{i}": {"w": m} for i, m in enumerate(masks)}
+    task_masks["none_task"] = None                                   # mask_loader.py:589-594
+    for strat in ("union", "intersection", "majority"):
+        comb = ref_masks.combine_masks(task_masks, strategy=strat, device="cpu", verbose=False)
+        out[f"combined_{strat}"] = comb["w"].numpy()
+    # even-N tie for majority (reference tests/test_mask_strategies.py): >= 0.5 * n
+    even = ref_masks.compute_majority_mask(masks[:4])
+    out["majority_even4"] = even.numpy()
+    union = torch.from_numpy(out["combined_union"])
+    sig = [ref_masks.apply_mask_to_tensor(d, union) for d in deltas]
+    noi = [ref_masks.get_unmasked_portion(d, union) for d in deltas]
+    out["signal"] = torch.stack(sig).numpy()
+    out["noise"] = torch.stack(noi).numpy()
+    back = ref_masks.reconstruct_from_masked(sig[0], noi[0], union, deltas[0].shape)
+    assert torch.equal(back, deltas[0])
+    out["scatter_signal_only"] = ref_masks.reconstruct_from_masked(sig[1], None, union,
+                                                                   deltas[1].shape).numpy()
+    mb = ref_basis.construct_masked_basis(sig, noi, energy_threshold=0.9, max_rank=None, center=True,
+                                          device="cpu", include_noise=True, verbose=False)
+    for region in ("masked", "noise"):
+        b = mb[region]
+        out[f"{region}__S"] = b["singular_values"].numpy()
+        out[f"{region}__k"] = np.int64(b["k"])
+        out[f"{region}__energy"] = np.float64(b["energy_retained"])
+        out[f"{region}__D"] = np.int64(b["D"])
+        out[f"{region}__mean"] = b["mean"].squeeze(1).numpy()
+    none_case = ref_basis.construct_masked_basis([], None, verbose=False)
+    assert none_case == {"masked": None, "noise": None}
+    save("masks.npz", **out)
+
+
+# ------------------------------------------------------------------------------- pipeline
+def gen_pipeline():
+    """cli.py:317-361 + compress.py:173-207 over a toy model; pins dict layout and numbers."""
+    shapes = {"blk.0.attn.weight": (48, 32), "blk.0.attn.bias": (48,), "blk.1.mlp.weight": (64, 48)}
+    tasks = ["Cars", "DTD", "EuroSAT", "GTSRB"]
+    cfg = types.SimpleNamespace(svd_low_bits=4, svd_rtvq_stages=2, svd_include_noise=True,
+                                svd_min_mask_size=10, svd_energy_threshold=0.9, svd_max_rank=64,
+                                svd_center=True, svd_fp16=True)
+    g = torch.Generator().manual_seed(5)
+    task_vectors = {t: {} for t in tasks}
+    masks = {}
+    out = {}
+    for pi, (pname, shp) in enumerate(sorted(shapes.items())):
+        numel = int(np.prod(shp))
+        ds = synthetic_deltas(numel, len(tasks), 100 + pi)
+        for t, d in zip(tasks, ds):
+            task_vectors[t][pname] = d.view(shp)
+        out[f"in__{pname}"] = torch.stack(ds).numpy()
+        if pname.endswith("weight"):
+            per_task = [torch.rand(shp, generator=g) > 0.6 for _ in tasks]
+            masks[pname] = ref_masks.compute_union_mask(per_task)
+            out[f"mask__{pname}"] = masks[pname].numpy()
+    # Step 4 body (cli.py:317-361)
+    bases = {}
+    for pname in sorted(shapes):
+        mask = masks.get(pname)
+        md, ud = [], []
+        for t in tasks:
+            delta = task_vectors[t][pname]
+            if mask is not None and mask.shape == delta.shape:
+                if mask.sum() >= cfg.svd_min_mask_size:
+                    md.append(ref_masks.apply_mask_to_tensor(delta, mask))
+                    if cfg.svd_include_noise:
+                        ud.append(ref_masks.get_unmasked_portion(delta, mask))
+            else:
+                md.append(delta.flatten())
+        basis = ref_basis.construct_masked_basis(md, ud if cfg.svd_include_noise else None,
+                                                 energy_threshold=cfg.svd_energy_threshold,
+                                                 max_rank=cfg.svd_max_rank, center=cfg.svd_center,
+                                                 device="cpu", include_noise=cfg.svd_include_noise)
+        for region in ("masked", "noise"):
+            if basis.get(region) is not None:
+                basis[region]["U_high"] = basis[region]["U_high"].half()
+                basis[region]["U_low"] = basis[region]["U_low"].half()
+        bases[pname] = basis
+    compressed = ref_compress.compress_all_parameters(task_vectors, masks, bases, cfg, device="cpu")
+    layout = {}
+    quant = ref_rtvq.RTVQQuantizer(cfg.svd_low_bits, cfg.svd_rtvq_stages)
+    for pname in sorted(compressed):
+        layout[pname] = {}
+        for region in ("masked", "noise"):
+            b = bases[pname][region]
+            layout[pname][f"basis_{region}"] = None if b is None else sorted(b.keys())
+            if b is not None:
+                out[f"basis__{pname}__{region}__S"] = b["singular_values"].numpy()
+                out[f"basis__{pname}__{region}__k"] = np.int64(b["k"])
+                out[f"basis__{pname}__{region}__D"] = np.int64(b["D"])
+                out[f"basis__{pname}__{region}__energy"] = np.float64(b["energy_retained"])
+        for t in tasks:
+            art = compressed[pname][t]
+            layout[pname][t] = {r: (None if art[r] is None else sorted(art[r].keys()))
+                                for r in sorted(art.keys())}
+            for region, bkey in (("masked", "masked"), ("unmasked", "noise")):
+                a = art[region]
+                if a is None:
+                    continue
+                tag = f"coef__{pname}__{t}__{region}__"
+                out[tag + "c_high_fp16"] = a["c_high_fp16"].numpy()
+                payload_arrays(tag, a["c_low_quant"], out)
+                b = bases[pname][bkey]
+                rec = ref_merge.reconstruct_from_coefficients(
+                    a["c_high_fp16"].float(), quant.dequantize(a["c_low_quant"]).float(),
+                    b["U_high"], b["U_low"], "cpu", mean=b["mean"])
+                out[tag + "recon"] = rec.numpy()
+    out["layout_json"] = np.array(json.dumps(layout, sort_keys=True))
+    out["tasks"] = np.array(tasks)
+    out["params"] = np.array(sorted(shapes))
+    save("pipeline.npz", **out)
+
+
+# ------------------------------------------------------------------------------- rank KATs
+def gen_rank():
+    out = {}
+    spectra = {
+        "decay8": [10.0, 5.0, 2.0, 1.0, 0.5, 0.2, 0.1, 0.05],
+        "tiny": [10.0, 1e-10, 1e-12],
+        "dominant": [100.0, 0.01, 0.001],
+        "four": [4.0, 3.0, 2.0, 1.0],
+        "five": [10.0, 5.0, 2.0, 1.0, 0.5],
+        "zeros": [0.0, 0.0, 0.0],
+        "ones100": [1.0] * 100,
+    }
+    for name, vals in spectra.items():
+        S = torch.tensor(vals)
+        out[f"{name}__S"] = S.numpy()
+        out[f"{name}__cum"] = ref_basis.compute_energy_spectrum(S).numpy()
+        for thr in (0.5, 0.9, 0.95, 0.99, 0.999, 1.0):
+            for mr in (None, 2, 10):
+                key = f"{name}__k__thr{thr}__mr{mr}"
+                out[key] = np.int64(ref_basis.select_rank(S, thr, mr))
+        out[f"{name}__k__minrank2"] = np.int64(ref_basis.select_rank(S, 0.999, None, min_rank=2))
+    save("rank_kats.npz", **out)
+
+
+if __name__ == "__main__":
+    gen_rtvq()
+    gen_rtvq_large()
+    gen_rank()
+    gen_basis()
+    gen_config1()
+    gen_masks()
+    gen_pipeline()
