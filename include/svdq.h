@@ -1,0 +1,179 @@
+/*
+ * include/svdq.h -- C ABI of libsvdq_hip.so: the MI355X (gfx950) SVD-Hybrid task-vector
+ * compressor hot path.  extern "C", plain pointers and sizes, no framework types.
+ *
+ * The reference (mgradyn/SVD-Quantization-Task-Merging) is pure Python and has NO FFI /
+ * operator interface for this path: its boundary is a set of
+ * Python callables exchanging dicts.  Each entry point below states which of those
+ * callables (reference file:line) it replaces; the Python host layer in
+ * svd-quantization-task-merging_amd/ rebuilds the reference's exact signatures and dict
+ * layouts on top of this ABI through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - Every pointer named *_dev is a DEVICE pointer (HBM).  Nothing here copies to or from
+ *    the host except svdq_plan_create (tables, once) -- no entry point synchronises the
+ *    stream or the device; all work is enqueued on `stream` (a hipStream_t passed as void*).
+ *  - Return value: SVDQ_OK or a negative SVDQ_E* code; svdq_last_error() gives text.
+ *  - Task delta buffers are fp32, contiguous, one buffer per (parameter, task), base
+ *    address 16-byte aligned; the [D,N] stack of basis.py:103 is never materialised.
+ *  - N (tasks) <= SVDQ_MAX_TASKS.
+ */
+#ifndef SVDQ_H
+#define SVDQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVDQ_ABI_VERSION 1
+#define SVDQ_MAX_TASKS 32
+#define SVDQ_MAX_STAGES 8
+
+enum {
+    SVDQ_OK = 0,
+    SVDQ_EINVAL = -1,     /* bad argument (the reference raises ValueError) */
+    SVDQ_EHIP = -2,       /* HIP runtime error */
+    SVDQ_EUNSUPPORTED = -3
+};
+
+enum { SVDQ_MASK_UNION = 0, SVDQ_MASK_INTERSECTION = 1, SVDQ_MASK_MAJORITY = 2 };
+
+/* Run-wide settings; field names follow SVDHybridConfig (reference src/svd_hybrid/config.py:157-205). */
+typedef struct svdq_config {
+    float   energy_threshold;  /* svd_energy_threshold, (0,1]                       */
+    int32_t max_rank;          /* svd_max_rank, <= 0 means None                      */
+    int32_t center;            /* svd_center                                         */
+    int32_t fp16;              /* svd_fp16: basis stored (and projected with) fp16   */
+    int32_t low_bits;          /* svd_low_bits 1..8                                  */
+    int32_t rtvq_stages;       /* svd_rtvq_stages 1..SVDQ_MAX_STAGES                 */
+    int32_t unit_rows;         /* 0 = auto; rows per work unit (multiple of 256)     */
+    int32_t reserved;
+} svdq_config;
+
+/* Byte sizes / strides the caller needs to allocate outputs (all device memory). */
+typedef struct svdq_sizes {
+    int64_t workspace_bytes;   /* scratch: Gram / projection partials, W, ranks               */
+    int64_t basis_bytes;       /* packed U buffer (see svdq_plan_basis_layout)                 */
+    int64_t mean_floats;       /* packed mean buffer, floats                                   */
+    int64_t small_bytes;       /* packed small artifacts (see svdq_small_layout)               */
+    int32_t n_units;           /* work units (one wavefront each) in passes 1 and 2            */
+    int32_t n_slots;           /* partial-sum slots                                            */
+} svdq_sizes;
+
+/* Offsets (bytes) of the typed arrays inside the packed "small artifacts" buffer.
+ * P = parameters, N = tasks, S = stages.  Everything a caller needs on the host after a
+ * run is in this one buffer, so one D2H copy fetches it. */
+typedef struct svdq_small_layout {
+    int64_t sigma_off;      /* float   [P][N]       singular values, descending (first r valid)   */
+    int64_t k_off;          /* int32   [P]          selected rank k                                */
+    int64_t r_off;          /* int32   [P]          r = min(D, N) = number of singular values      */
+    int64_t energy_off;     /* float   [P]          energy_retained = cum_energy[k-1]              */
+    int64_t rows_off;       /* int64   [P]          rows actually processed (D, or mask.sum())     */
+    int64_t chigh_off;      /* uint16  [P][N][N]    fp16 bits of c_high per task (first k valid)   */
+    int64_t codes_off;      /* uint8   [P][N][S][N] RTVQ codes of c_low per task (first r-k valid) */
+    int64_t scale_off;      /* float   [P][N][S]                                                   */
+    int64_t zp_off;         /* float   [P][N][S]                                                   */
+    int64_t rnorm_off;      /* float   [P][N][S]    residual norm before each stage                */
+    int64_t coef_off;       /* float   [P][N][N]    fp32 coefficients c[t][i] before rounding      */
+    int64_t total_bytes;
+} svdq_small_layout;
+
+typedef struct svdq_plan svdq_plan;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int         svdq_abi_version(void);
+const char *svdq_last_error(void);
+
+/* ---- plan: a ragged batch of P parameter tensors x N tasks -------------------------------
+ * rows[p] = D_p, the element count of parameter p (upper bound when a mask is applied on
+ * device).  Replaces the Python loop state of cli.py:317 (Step 4) / compress.py:187 (Step 5).
+ * Allocates and fills small device tables (hipMalloc + hipMemcpy): call outside timed code. */
+int  svdq_plan_create(svdq_plan **plan, int32_t n_tasks, int32_t n_params, const int64_t *rows,
+                      const svdq_config *cfg);
+void svdq_plan_destroy(svdq_plan *plan);
+int  svdq_plan_sizes(const svdq_plan *plan, svdq_sizes *out);
+int  svdq_plan_small_layout(const svdq_plan *plan, svdq_small_layout *out);
+/* Per parameter: byte offset of its slab in the packed basis buffer and float offset of its
+ * mean in the packed mean buffer.  Inside a slab (rows = rows processed, e = 2 or 4 bytes):
+ *   U_high [rows, k]     row-major at slab + 0
+ *   U_low  [rows, r-k]   row-major at slab + align256(rows * k * e)
+ * i.e. the two .contiguous() tensors of basis.py:363-364, already cast per cli.py:354-361. */
+int  svdq_plan_basis_layout(const svdq_plan *plan, int64_t *slab_off_bytes /*[P]*/,
+                            int64_t *mean_off_floats /*[P]*/);
+
+/* ---- pass 1: centred Gram  (stack_and_center basis.py:63-113 + first half of compute_svd
+ *      basis.py:216-249).  G_p = Tc^T Tc accumulated by fp32 MFMA per 256-row block and fp64
+ *      across blocks; one fp64 partial per work unit goes to the workspace.
+ *      delta_ptrs_dev: device array [P*N] of const float* (parameter-major, task order =
+ *      column order of basis.py:103).  rows_dev: optional device int64 [P] overriding rows
+ *      (mask.sum() computed on device); NULL = plan rows. */
+int svdq_gram_center(const svdq_plan *plan, const void *delta_ptrs_dev, const int64_t *rows_dev,
+                     void *workspace_dev, void *stream);
+
+/* ---- N x N eigen-solve + rank selection  (second half of compute_svd; compute_energy_spectrum
+ *      basis.py:116-156; select_rank basis.py:159-213; energy_retained basis.py:367).
+ *      Cyclic Jacobi in fp64, sigma = sqrt(lambda) -> fp32, fp32 cumsum rule of the reference.
+ *      Writes sigma / k / r / energy / rows into small_dev and W = V Sigma^-1 into the workspace. */
+int svdq_eig_rank_select(const svdq_plan *plan, const int64_t *rows_dev, void *workspace_dev,
+                         void *small_dev, void *stream);
+
+/* ---- pass 2: basis + projection  (U = Tc W and the split of basis.py:363-364, the fp16 cast
+ *      of cli.py:354-361, mean of basis.py:109, and project_to_basis compress.py:6-21 for all
+ *      N tasks against the ROUNDED basis, fused in one streaming pass).
+ *      Writes U_high/U_low slabs into basis_dev, means into mean_dev (NULL allowed when
+ *      center == 0) and fp64 projection partials into the workspace. */
+int svdq_basis_project(const svdq_plan *plan, const void *delta_ptrs_dev, const int64_t *rows_dev,
+                       void *workspace_dev, const void *small_dev, void *basis_dev, float *mean_dev,
+                       void *stream);
+
+/* ---- coefficient epilogue  (compress_single_task compress.py:42-56: c_high -> fp16,
+ *      c_low -> RTVQQuantizer.quantize rtvq.py:39-82, for every (parameter, task)). */
+int svdq_coeff_quantize(const svdq_plan *plan, void *workspace_dev, void *small_dev, void *stream);
+
+/* ---- all four stages back to back on one stream (cli.py Step 4 + Step 5 for the batch) ---- */
+int svdq_compress(const svdq_plan *plan, const void *delta_ptrs_dev, const int64_t *rows_dev,
+                  void *workspace_dev, void *small_dev, void *basis_dev, float *mean_dev, void *stream);
+
+/* ---- standalone quantizer on one large tensor  (RTVQQuantizer.quantize / dequantize
+ *      rtvq.py:106-139; asymmetric_quantization rtvq.py:4-27 == quantization_utils.py:76-99).
+ *      codes_dev: uint8 [stages][code_stride] (code_stride % 4 == 0, >= n; first n of each
+ *      row valid); scale/zp/rnorm_dev: float [stages];
+ *      work_dev: svdq_rtvq_work_bytes(n) bytes of scratch. */
+int64_t svdq_rtvq_work_bytes(int64_t n);
+int svdq_rtvq_quantize(const float *x_dev, int64_t n, int32_t bits, int32_t stages,
+                       uint8_t *codes_dev, int64_t code_stride, float *scale_dev, float *zp_dev,
+                       float *rnorm_dev, void *work_dev, void *stream);
+int svdq_rtvq_dequantize(const uint8_t *codes_dev, int64_t code_stride, int64_t n, int32_t stages,
+                         const float *scale_dev, const float *zp_dev, float *out_dev, void *stream);
+
+/* ---- standalone projection for callers that bring their own basis
+ *      (project_to_basis compress.py:6-21 with the mean subtraction of compress.py:35-37):
+ *      c_out[i] = sum_d float(U[d][i]) * (delta[d] - mean[d]),  i < k from U_high [rows,k],
+ *      then i < k+nl from U_low [rows,nl]; both row-major, fp16 (u_fp16 != 0) or fp32;
+ *      mean may be NULL; k + nl <= 32.  work_dev: svdq_project_work_bytes(rows, k+nl) bytes. */
+int64_t svdq_project_work_bytes(int64_t rows, int32_t ncols);
+int svdq_project(const void *u_high_dev, const void *u_low_dev, int32_t u_fp16, int64_t rows,
+                 int32_t k, int32_t nl, const float *delta_dev, const float *mean_dev,
+                 float *c_out_dev, void *work_dev, void *stream);
+
+/* ---- masks  (compute_union/intersection/majority_mask mask_loader.py:412-485;
+ *      apply_mask_to_tensor / get_unmasked_portion mask_loader.py:651-709).
+ *      mask_ptrs_dev: device array [n_masks] of const uint8_t* (torch.bool storage).
+ *      svdq_mask_combine writes the combined mask (0/1 bytes) and its popcount.
+ *      svdq_mask_compact: order-preserving compaction of n_src fp32 buffers under one mask
+ *      (invert != 0 selects the False positions); count_dev receives the selected count.
+ *      work_dev: svdq_mask_work_bytes(numel) bytes. */
+int64_t svdq_mask_work_bytes(int64_t numel);
+int svdq_mask_combine(const void *mask_ptrs_dev, int32_t n_masks, int64_t numel, int32_t strategy,
+                      uint8_t *out_dev, int64_t *count_dev, void *work_dev, void *stream);
+int svdq_mask_compact(const void *src_ptrs_dev, const void *dst_ptrs_dev, int32_t n_src,
+                      const uint8_t *mask_dev, int32_t invert, int64_t numel, int64_t *count_dev,
+                      void *work_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVDQ_H */

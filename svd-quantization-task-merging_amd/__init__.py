@@ -1,0 +1,29 @@
+"""
+svdq_amd -- MI355X-native SVD-Hybrid task-vector compressor (hot path of
+mgradyn/SVD-Quantization-Task-Merging, src/svd_hybrid/{basis,compress,rtvq,mask_loader}.py and
+quantization_utils.py), computed by hand-written gfx950 HIP kernels behind a C ABI
+(include/svdq.h, libsvdq_hip.so).  Import as ``svdq_amd`` (svdq_amd.py at the repo root aliases
+this directory, whose name is not a Python identifier).
+
+The function names, argument orders, defaults and returned dict layouts are the reference's.
+There is no CPU implementation in this package: a missing library raises RuntimeError.
+"""
+from . import _native
+from .config import SVDHybridConfig
+from .rtvq import (RTVQQuantizer, asymmetric_quantization, asymmetric_dequantization,
+                   multistage_residual_quantization, multistage_residual_dequantization,
+                   estimate_compression_ratio)
+from .basis import (construct_basis, construct_masked_basis, select_rank, compute_energy_spectrum, compute_svd,
+                    stack_and_center, compute_energy_statistics)
+from .compress import (project_to_basis, compress_single_task, compress_masked_regions, compress_parameter,
+                       compress_all_parameters)
+from .mask_loader import (combine_masks, compute_union_mask, compute_intersection_mask, compute_majority_mask,
+                          apply_mask_to_tensor, get_unmasked_portion, reconstruct_from_masked)
+from .merge import dequantize_and_average, reconstruct_from_coefficients
+from .driver import build_bases, run_basis_and_compress
+from .pipeline import CompressPlan, compress_batch
+
+# aliases named by BASELINE.json's north_star (quantization_utils.py)
+dequantize_asymmetric = asymmetric_dequantization
+
+__all__ = [n for n in dir() if not n.startswith("_")]

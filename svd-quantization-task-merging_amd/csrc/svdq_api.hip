@@ -1,0 +1,258 @@
+// svdq_api.hip -- extern "C" entry points of libsvdq_hip.so (declared in include/svdq.h).
+// Host-side only: builds the unit / parameter tables of a plan and enqueues the kernels.
+
+#include "svdq_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void svdq_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            svdq_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SVDQ_EHIP;                                                           \
+        }                                                                               \
+    } while (0)
+
+extern "C" int svdq_abi_version(void) { return SVDQ_ABI_VERSION; }
+extern "C" const char *svdq_last_error(void) { return g_err; }
+
+static int32_t auto_unit_rows(int64_t D) {
+    // about 256 units for the large matrices (load balance over 256 CUs x ~12 waves),
+    // never fewer than 4 blocks per unit so the per-unit fp64 partial stays < 1 % of the traffic
+    int64_t ur = svdq_align_up((D + 255) / 256, SVDQ_BLK_ROWS);
+    if (ur < 4 * SVDQ_BLK_ROWS) ur = 4 * SVDQ_BLK_ROWS;
+    return (int32_t)ur;
+}
+
+extern "C" int svdq_plan_create(svdq_plan **out, int32_t n_tasks, int32_t n_params, const int64_t *rows,
+                                const svdq_config *cfg) {
+    if (!out || !rows || !cfg) {
+        svdq_set_error("null argument");
+        return SVDQ_EINVAL;
+    }
+    if (n_tasks < 1 || n_tasks > SVDQ_MAX_TASKS) {
+        svdq_set_error("n_tasks must be in [1, %d], got %d", SVDQ_MAX_TASKS, n_tasks);
+        return SVDQ_EINVAL;
+    }
+    if (n_params < 1) {
+        svdq_set_error("Empty delta list");  // basis.py:285
+        return SVDQ_EINVAL;
+    }
+    // SVDHybridConfig.__post_init__ (config.py:207-234)
+    if (!(cfg->energy_threshold > 0.f && cfg->energy_threshold <= 1.f)) {
+        svdq_set_error("Energy threshold must be in (0, 1], got %g", cfg->energy_threshold);
+        return SVDQ_EINVAL;
+    }
+    if (cfg->low_bits < 1 || cfg->low_bits > 8) {
+        svdq_set_error("Low bits must be in [1, 8], got %d", cfg->low_bits);
+        return SVDQ_EINVAL;
+    }
+    if (cfg->rtvq_stages < 1 || cfg->rtvq_stages > SVDQ_MAX_STAGES) {
+        svdq_set_error("RTVQ stages must be in [1, %d], got %d", SVDQ_MAX_STAGES, cfg->rtvq_stages);
+        return SVDQ_EINVAL;
+    }
+    if (cfg->unit_rows < 0 || cfg->unit_rows % SVDQ_BLK_ROWS != 0) {
+        svdq_set_error("unit_rows must be 0 or a multiple of %d", SVDQ_BLK_ROWS);
+        return SVDQ_EINVAL;
+    }
+    for (int p = 0; p < n_params; ++p)
+        if (rows[p] < 1) {
+            svdq_set_error("parameter %d has %lld rows", p, (long long)rows[p]);
+            return SVDQ_EINVAL;
+        }
+
+    svdq_plan *pl = (svdq_plan *)calloc(1, sizeof(svdq_plan));
+    pl->n_tasks = n_tasks;
+    pl->n_params = n_params;
+    pl->cfg = *cfg;
+    pl->ntp = svdq_ntp(n_tasks);
+    pl->pack = pl->ntp <= 8 ? 2 : 1;
+    const int es = cfg->fp16 ? 2 : 4;
+    const int64_t N = n_tasks;
+
+    pl->h_params = (SvdqParam *)calloc(n_params, sizeof(SvdqParam));
+    int64_t n_units = 0, basis_bytes = 0, mean_floats = 0;
+    for (int p = 0; p < n_params; ++p) {
+        const int64_t D = rows[p];
+        const int32_t ur = cfg->unit_rows > 0 ? cfg->unit_rows : auto_unit_rows(D);
+        const int64_t cnt = (D + ur - 1) / ur;
+        SvdqParam &pd = pl->h_params[p];
+        pd.rows = D;
+        pd.slab_off = basis_bytes;
+        pd.mean_off = mean_floats;
+        pd.unit_begin = (int32_t)n_units;
+        pd.unit_count = (int32_t)cnt;
+        n_units += cnt;
+        const int64_t r = D < N ? D : N;
+        basis_bytes += svdq_align_up(D * r * es, 256) + 256;  // + room for the aligned U_low start
+        mean_floats += svdq_align_up(D, 64);
+    }
+    if (n_units > 0x7fffffff / 4) {
+        svdq_set_error("too many work units (%lld)", (long long)n_units);
+        free(pl->h_params);
+        free(pl);
+        return SVDQ_EINVAL;
+    }
+    pl->n_units = (int32_t)n_units;
+    pl->n_slots = pl->n_units * pl->pack;
+    pl->h_units = (SvdqUnit *)calloc(n_units, sizeof(SvdqUnit));
+    for (int p = 0; p < n_params; ++p) {
+        const int64_t D = rows[p];
+        const int32_t ur = cfg->unit_rows > 0 ? cfg->unit_rows : auto_unit_rows(D);
+        const SvdqParam &pd = pl->h_params[p];
+        for (int32_t i = 0; i < pd.unit_count; ++i) {
+            SvdqUnit &u = pl->h_units[pd.unit_begin + i];
+            u.param = p;
+            u.row0 = (int64_t)i * ur;
+            u.nrows = (int32_t)((D - u.row0) < ur ? (D - u.row0) : ur);
+        }
+    }
+
+    // workspace
+    const int64_t nn = N * N;
+    int64_t off = 0;
+    pl->ws_gram_off = off;
+    off += svdq_align_up((int64_t)pl->n_slots * nn * 8, 256);
+    pl->ws_cpart_off = off;
+    off += svdq_align_up((int64_t)pl->n_slots * nn * 8, 256);
+    pl->ws_w_off = off;
+    off += svdq_align_up((int64_t)n_params * nn * 4, 256);
+    pl->sizes.workspace_bytes = off;
+    pl->sizes.basis_bytes = basis_bytes;
+    pl->sizes.mean_floats = mean_floats;
+    pl->sizes.n_units = pl->n_units;
+    pl->sizes.n_slots = pl->n_slots;
+
+    // small artifacts
+    const int64_t P = n_params, S = cfg->rtvq_stages;
+    svdq_small_layout &L = pl->small;
+    off = 0;
+    L.sigma_off = off;  off += svdq_align_up(P * N * 4, 64);
+    L.k_off = off;      off += svdq_align_up(P * 4, 64);
+    L.r_off = off;      off += svdq_align_up(P * 4, 64);
+    L.energy_off = off; off += svdq_align_up(P * 4, 64);
+    L.rows_off = off;   off += svdq_align_up(P * 8, 64);
+    L.chigh_off = off;  off += svdq_align_up(P * nn * 2, 64);
+    L.codes_off = off;  off += svdq_align_up(P * N * S * N, 64);
+    L.scale_off = off;  off += svdq_align_up(P * N * S * 4, 64);
+    L.zp_off = off;     off += svdq_align_up(P * N * S * 4, 64);
+    L.rnorm_off = off;  off += svdq_align_up(P * N * S * 4, 64);
+    L.coef_off = off;   off += svdq_align_up(P * nn * 4, 64);
+    L.total_bytes = off;
+    pl->sizes.small_bytes = off;
+
+    hipError_t e = hipMalloc((void **)&pl->d_params, sizeof(SvdqParam) * n_params);
+    if (e == hipSuccess) e = hipMalloc((void **)&pl->d_units, sizeof(SvdqUnit) * n_units);
+    if (e == hipSuccess)
+        e = hipMemcpy(pl->d_params, pl->h_params, sizeof(SvdqParam) * n_params, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d_units, pl->h_units, sizeof(SvdqUnit) * n_units, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        svdq_set_error("plan table upload failed: %s", hipGetErrorString(e));
+        svdq_plan_destroy(pl);
+        return SVDQ_EHIP;
+    }
+    *out = pl;
+    return SVDQ_OK;
+}
+
+extern "C" void svdq_plan_destroy(svdq_plan *pl) {
+    if (!pl) return;
+    if (pl->d_params) (void)hipFree(pl->d_params);
+    if (pl->d_units) (void)hipFree(pl->d_units);
+    free(pl->h_params);
+    free(pl->h_units);
+    free(pl);
+}
+
+extern "C" int svdq_plan_sizes(const svdq_plan *pl, svdq_sizes *out) {
+    if (!pl || !out) return SVDQ_EINVAL;
+    *out = pl->sizes;
+    return SVDQ_OK;
+}
+
+extern "C" int svdq_plan_small_layout(const svdq_plan *pl, svdq_small_layout *out) {
+    if (!pl || !out) return SVDQ_EINVAL;
+    *out = pl->small;
+    return SVDQ_OK;
+}
+
+extern "C" int svdq_plan_basis_layout(const svdq_plan *pl, int64_t *slab_off, int64_t *mean_off) {
+    if (!pl) return SVDQ_EINVAL;
+    for (int p = 0; p < pl->n_params; ++p) {
+        if (slab_off) slab_off[p] = pl->h_params[p].slab_off;
+        if (mean_off) mean_off[p] = pl->h_params[p].mean_off;
+    }
+    return SVDQ_OK;
+}
+
+static inline uint8_t *ws(void *base, int64_t off) { return reinterpret_cast<uint8_t *>(base) + off; }
+
+extern "C" int svdq_gram_center(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                                void *stream) {
+    if (!pl || !ptrs || !workspace) {
+        svdq_set_error("null argument");
+        return SVDQ_EINVAL;
+    }
+    return svdq_launch_gram(pl, ptrs, rows_dev, reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off)),
+                            (hipStream_t)stream);
+}
+
+extern "C" int svdq_eig_rank_select(const svdq_plan *pl, const int64_t *rows_dev, void *workspace, void *small,
+                                    void *stream) {
+    if (!pl || !workspace || !small) {
+        svdq_set_error("null argument");
+        return SVDQ_EINVAL;
+    }
+    return svdq_launch_eig(pl, rows_dev, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram_off)),
+                           reinterpret_cast<float *>(ws(workspace, pl->ws_w_off)), reinterpret_cast<uint8_t *>(small),
+                           (hipStream_t)stream);
+}
+
+extern "C" int svdq_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                                  const void *small, void *basis, float *mean, void *stream) {
+    if (!pl || !ptrs || !workspace || !small || !basis) {
+        svdq_set_error("null argument");
+        return SVDQ_EINVAL;
+    }
+    if ((reinterpret_cast<uintptr_t>(basis) & 255) != 0) {
+        svdq_set_error("basis buffer must be 256-byte aligned");
+        return SVDQ_EINVAL;
+    }
+    const uint8_t *sm = reinterpret_cast<const uint8_t *>(small);
+    return svdq_launch_basis_project(pl, ptrs, rows_dev, reinterpret_cast<const float *>(ws(workspace, pl->ws_w_off)),
+                                     reinterpret_cast<const int32_t *>(sm + pl->small.k_off),
+                                     reinterpret_cast<const int32_t *>(sm + pl->small.r_off),
+                                     reinterpret_cast<uint8_t *>(basis), mean,
+                                     reinterpret_cast<double *>(ws(workspace, pl->ws_cpart_off)), (hipStream_t)stream);
+}
+
+extern "C" int svdq_coeff_quantize(const svdq_plan *pl, void *workspace, void *small, void *stream) {
+    if (!pl || !workspace || !small) {
+        svdq_set_error("null argument");
+        return SVDQ_EINVAL;
+    }
+    return svdq_launch_coeff(pl, reinterpret_cast<const double *>(ws(workspace, pl->ws_cpart_off)),
+                             reinterpret_cast<uint8_t *>(small), (hipStream_t)stream);
+}
+
+extern "C" int svdq_compress(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                             void *small, void *basis, float *mean, void *stream) {
+    int rc = svdq_gram_center(pl, ptrs, rows_dev, workspace, stream);
+    if (rc == SVDQ_OK) rc = svdq_eig_rank_select(pl, rows_dev, workspace, small, stream);
+    if (rc == SVDQ_OK) rc = svdq_basis_project(pl, ptrs, rows_dev, workspace, small, basis, mean, stream);
+    if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
+    return rc;
+}

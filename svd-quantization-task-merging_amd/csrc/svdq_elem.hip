@@ -1,0 +1,509 @@
+// svdq_elem.hip -- element-wise / scan kernels: the standalone multi-stage quantizer on large
+// tensors (RTVQQuantizer.quantize/dequantize, rtvq.py:39-139) and the mask operators
+// (mask_loader.py:412-485, 651-709).  Compiled with -ffp-contract=off.
+//
+// Quantizer on n elements, S stages, all on device, no host round trip:
+//   k_rtvq_stats   x -> per-block {min, max, has_nan, sum of squares}        (read 4n)
+//   per stage s:
+//     k_rtvq_params  block partials -> scale_s, zero_point_s, residual_norm_s (fixed order)
+//     k_rtvq_apply   residual -> codes_s (1 B/elem), next residual, next stage's partials
+//                                                                            (read 4n, write 5n)
+// Algorithmic bytes n*(4+S); this schedule moves n*(4 + S*9 - 4) because stage s+1's min/max
+// depends on stage s's scale.
+
+#include "svdq_common.h"
+#include <hip/hip_fp16.h>
+
+#define ELT_THREADS 256
+#define RTVQ_MAX_BLOCKS 2048
+
+struct RtvqPartial {
+    float mn, mx;
+    int has_nan, pad;
+    double ss;
+};
+
+struct RtvqStage {
+    float scale, zp;
+};
+
+typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void stat_acc(float x, float &mn, float &mx, int &has_nan, double &ss) {
+    if (x != x) has_nan = 1;
+    mn = x < mn ? x : mn;
+    mx = x > mx ? x : mx;
+    ss += (double)x * (double)x;
+}
+
+// block-level combine of per-thread stats, result written by thread 0
+__device__ void stats_block_reduce(float mn, float mx, int has_nan, double ss, RtvqPartial *dst) {
+    __shared__ float s_mn[ELT_THREADS], s_mx[ELT_THREADS];
+    __shared__ int s_nan[ELT_THREADS];
+    __shared__ double s_ss[ELT_THREADS];
+    const int tid = threadIdx.x;
+    s_mn[tid] = mn;
+    s_mx[tid] = mx;
+    s_nan[tid] = has_nan;
+    s_ss[tid] = ss;
+    __syncthreads();
+    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
+        if (tid < off) {
+            s_mn[tid] = s_mn[tid + off] < s_mn[tid] ? s_mn[tid + off] : s_mn[tid];
+            s_mx[tid] = s_mx[tid + off] > s_mx[tid] ? s_mx[tid + off] : s_mx[tid];
+            s_nan[tid] |= s_nan[tid + off];
+            s_ss[tid] += s_ss[tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        dst->mn = s_mn[0];
+        dst->mx = s_mx[0];
+        dst->has_nan = s_nan[0];
+        dst->pad = 0;
+        dst->ss = s_ss[0];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(ELT_THREADS) void k_rtvq_stats(const float *__restrict__ x, int64_t n,
+                                                            RtvqPartial *__restrict__ part) {
+    const int64_t nvec = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * ELT_THREADS;
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    int has_nan = 0;
+    double ss = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x; i < nvec; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stat_acc(v[e], mn, mx, has_nan, ss);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) stat_acc(x[(nvec << 2) + threadIdx.x], mn, mx, has_nan, ss);
+    stats_block_reduce(mn, mx, has_nan, ss, part + blockIdx.x);
+}
+
+// rtvq.py:10-18 for one stage, from the block partials (fixed order => deterministic norm)
+__global__ __launch_bounds__(64) void k_rtvq_params(const RtvqPartial *__restrict__ part, int nblk, int bits,
+                                                    int stage, RtvqStage *__restrict__ stg,
+                                                    float *__restrict__ scale_out, float *__restrict__ zp_out,
+                                                    float *__restrict__ rnorm_out) {
+    if (threadIdx.x != 0) return;
+    float mn = part[0].mn, mx = part[0].mx;
+    int has_nan = 0;
+    double ss = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        mn = part[b].mn < mn ? part[b].mn : mn;
+        mx = part[b].mx > mx ? part[b].mx : mx;
+        has_nan |= part[b].has_nan;
+        ss += part[b].ss;
+    }
+    if (has_nan) {  // torch min/max propagate NaN
+        mn = __builtin_nanf("");
+        mx = mn;
+    }
+    const float qmax = (float)((1 << bits) - 1);
+    // python-int / Tensor == Tensor.reciprocal() * int: two roundings (tests/golden/rtvq_cases.npz)
+    const float scale = __fmul_rn(__fdiv_rn(1.0f, __fsub_rn(mx, mn)), qmax);
+    const float zp = __fmul_rn(-1.0f, rintf(__fmul_rn(scale, mn)));
+    stg[stage].scale = scale;
+    stg[stage].zp = zp;
+    scale_out[stage] = scale;
+    zp_out[stage] = zp;
+    rnorm_out[stage] = (float)sqrt(ss);
+}
+
+__device__ __forceinline__ unsigned char quant_one(float x, float scale, float zp, float qmax, float &res) {
+    float vq = rintf(__fadd_rn(__fmul_rn(scale, x), zp));   // rtvq.py:20, two roundings
+    unsigned char q;
+    if (vq != vq) {
+        q = 0;                                               // NaN -> code 0 (reference CPU cast)
+    } else {
+        vq = vq < 0.f ? 0.f : (vq > qmax ? qmax : vq);
+        q = (unsigned char)vq;
+    }
+    const float deq = __fdiv_rn(__fsub_rn((float)q, zp), scale);   // rtvq.py:35
+    res = __fsub_rn(x, deq);                                       // rtvq.py:65
+    return q;
+}
+
+template <bool LAST>
+__global__ __launch_bounds__(ELT_THREADS) void k_rtvq_apply(const float *__restrict__ rin, float *__restrict__ rout,
+                                                            int64_t n, const RtvqStage *__restrict__ stg, int stage,
+                                                            int bits, uint8_t *__restrict__ codes,
+                                                            RtvqPartial *__restrict__ part) {
+    const float scale = stg[stage].scale, zp = stg[stage].zp;
+    const float qmax = (float)((1 << bits) - 1);
+    const int64_t nvec = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * ELT_THREADS;
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    int has_nan = 0;
+    double ss = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x; i < nvec; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(rin)[i];
+        f32x4 r;
+        u8x4 q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float re;
+            q[e] = quant_one(v[e], scale, zp, qmax, re);
+            r[e] = re;
+            if (!LAST) stat_acc(re, mn, mx, has_nan, ss);
+        }
+        reinterpret_cast<u8x4 *>(codes)[i] = q;
+        if (!LAST) reinterpret_cast<f32x4 *>(rout)[i] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nvec << 2) + threadIdx.x;
+        float re;
+        codes[i] = quant_one(rin[i], scale, zp, qmax, re);
+        if (!LAST) {
+            rout[i] = re;
+            stat_acc(re, mn, mx, has_nan, ss);
+        }
+    }
+    if (!LAST) stats_block_reduce(mn, mx, has_nan, ss, part + blockIdx.x);
+}
+
+// rtvq.py:85-103: ((0 + deq_0) + deq_1) + ...
+__global__ __launch_bounds__(ELT_THREADS) void k_rtvq_dequant(const uint8_t *__restrict__ codes, int64_t cstride,
+                                                              int64_t n, int stages,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ zp, float *__restrict__ out) {
+    const int64_t nvec = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * ELT_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x; i < nvec; i += stride) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < stages; ++s) {
+            const u8x4 q = reinterpret_cast<const u8x4 *>(codes + (size_t)s * cstride)[i];
+            const float sc = scale[s], z = zp[s];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __fadd_rn(acc[e], __fdiv_rn(__fsub_rn((float)q[e], z), sc));
+        }
+        reinterpret_cast<f32x4 *>(out)[i] = acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nvec << 2) + threadIdx.x;
+        float acc = 0.f;
+        for (int s = 0; s < stages; ++s)
+            acc = __fadd_rn(acc, __fdiv_rn(__fsub_rn((float)codes[(size_t)s * cstride + i], zp[s]), scale[s]));
+        out[i] = acc;
+    }
+}
+
+static int rtvq_grid(int64_t n) {
+    int64_t b = ((n >> 2) + ELT_THREADS * 4 - 1) / (ELT_THREADS * 4);
+    if (b < 1) b = 1;
+    if (b > RTVQ_MAX_BLOCKS) b = RTVQ_MAX_BLOCKS;
+    return (int)b;
+}
+
+extern "C" int64_t svdq_rtvq_work_bytes(int64_t n) {
+    return svdq_align_up(n * 4, 256) + (int64_t)RTVQ_MAX_BLOCKS * sizeof(RtvqPartial) + SVDQ_MAX_STAGES * sizeof(RtvqStage) +
+           256;
+}
+
+extern "C" int svdq_rtvq_quantize(const float *x, int64_t n, int32_t bits, int32_t stages, uint8_t *codes,
+                                  int64_t code_stride, float *scale, float *zp, float *rnorm, void *work,
+                                  void *stream) {
+    if (n < 1 || !x || !codes || !scale || !zp || !rnorm || !work) {
+        svdq_set_error("svdq_rtvq_quantize: bad argument (n must be >= 1; empty tensors are the caller's job)");
+        return SVDQ_EINVAL;
+    }
+    if (bits < 1 || bits > 8 || stages < 1 || stages > SVDQ_MAX_STAGES) {
+        svdq_set_error("svdq_rtvq_quantize: bits in [1,8], stages in [1,%d]", SVDQ_MAX_STAGES);
+        return SVDQ_EINVAL;
+    }
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(work) & 255) ||
+        (reinterpret_cast<uintptr_t>(codes) & 3) || (code_stride & 3) || code_stride < n) {
+        svdq_set_error("svdq_rtvq_quantize: x 16-byte, work 256-byte, codes 4-byte aligned; code_stride %% 4 == 0, >= n");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *wb = reinterpret_cast<uint8_t *>(work);
+    float *res = reinterpret_cast<float *>(wb);
+    RtvqPartial *part = reinterpret_cast<RtvqPartial *>(wb + svdq_align_up(n * 4, 256));
+    RtvqStage *stg = reinterpret_cast<RtvqStage *>(part + RTVQ_MAX_BLOCKS);
+    const int grid = rtvq_grid(n);
+    hipLaunchKernelGGL(k_rtvq_stats, dim3(grid), dim3(ELT_THREADS), 0, st, x, n, part);
+    for (int s = 0; s < stages; ++s) {
+        hipLaunchKernelGGL(k_rtvq_params, dim3(1), dim3(64), 0, st, part, grid, bits, s, stg, scale, zp, rnorm);
+        const float *rin = (s == 0) ? x : res;
+        if (s == stages - 1)
+            hipLaunchKernelGGL((k_rtvq_apply<true>), dim3(grid), dim3(ELT_THREADS), 0, st, rin, res, n, stg, s, bits,
+                               codes + (size_t)s * code_stride, part);
+        else
+            hipLaunchKernelGGL((k_rtvq_apply<false>), dim3(grid), dim3(ELT_THREADS), 0, st, rin, res, n, stg, s, bits,
+                               codes + (size_t)s * code_stride, part);
+    }
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+extern "C" int svdq_rtvq_dequantize(const uint8_t *codes, int64_t code_stride, int64_t n, int32_t stages,
+                                    const float *scale, const float *zp, float *out, void *stream) {
+    if (n < 1 || !codes || !scale || !zp || !out || stages < 1) {
+        svdq_set_error("svdq_rtvq_dequantize: bad argument");
+        return SVDQ_EINVAL;
+    }
+    if ((reinterpret_cast<uintptr_t>(codes) & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (code_stride & 3) ||
+        code_stride < n) {
+        svdq_set_error("svdq_rtvq_dequantize: codes 4-byte / out 16-byte aligned; code_stride %% 4 == 0, >= n");
+        return SVDQ_EINVAL;
+    }
+    hipLaunchKernelGGL(k_rtvq_dequant, dim3(rtvq_grid(n)), dim3(ELT_THREADS), 0, (hipStream_t)stream, codes,
+                       code_stride, n, stages, scale, zp, out);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+// ------------------------------------------------------------------------------------ masks
+#define MASK_TILE 2048  // elements per block: 256 threads x 8
+
+// mask_loader.py:412-485.  torch.bool storage is one byte per element, 0 or 1.
+__global__ __launch_bounds__(ELT_THREADS) void k_mask_combine(const uint8_t *const *__restrict__ masks, int n_masks,
+                                                              int64_t numel, int strategy, uint8_t *__restrict__ out,
+                                                              unsigned long long *__restrict__ count) {
+    const int64_t base = (int64_t)blockIdx.x * MASK_TILE + (int64_t)threadIdx.x * 8;
+    unsigned cnt = 0;
+    if (base < numel) {
+        const int lim = (int)((numel - base) < 8 ? (numel - base) : 8);
+        int votes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int m = 0; m < n_masks; ++m) {
+            const uint8_t *src = masks[m] + base;
+            for (int e = 0; e < lim; ++e) votes[e] += src[e] ? 1 : 0;
+        }
+        for (int e = 0; e < lim; ++e) {
+            int bit;
+            if (strategy == SVDQ_MASK_UNION)
+                bit = votes[e] > 0;
+            else if (strategy == SVDQ_MASK_INTERSECTION)
+                bit = votes[e] == n_masks;
+            else
+                bit = 2 * votes[e] >= n_masks;  // vote_sum >= 0.5 * len(masks), mask_loader.py:483
+            out[base + e] = (uint8_t)bit;
+            cnt += bit;
+        }
+    }
+    __shared__ unsigned s_cnt[ELT_THREADS];
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && s_cnt[0]) atomicAdd(count, (unsigned long long)s_cnt[0]);
+}
+
+__global__ __launch_bounds__(ELT_THREADS) void k_mask_count(const uint8_t *__restrict__ mask, int invert, int64_t numel,
+                                                            unsigned *__restrict__ tile_counts) {
+    const int64_t base = (int64_t)blockIdx.x * MASK_TILE + (int64_t)threadIdx.x * 8;
+    unsigned cnt = 0;
+    for (int e = 0; e < 8; ++e)
+        if (base + e < numel) cnt += ((mask[base + e] != 0) != (invert != 0)) ? 1u : 0u;
+    __shared__ unsigned s_cnt[ELT_THREADS];
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = s_cnt[0];
+}
+
+// exclusive scan of the tile counts (one block; ntiles <= a few thousand), total -> count_out
+__global__ __launch_bounds__(1024) void k_mask_scan(const unsigned *__restrict__ tile_counts, int ntiles,
+                                                    unsigned long long *__restrict__ tile_offsets,
+                                                    long long *__restrict__ count_out) {
+    __shared__ unsigned long long s[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned long long v = i < ntiles ? tile_counts[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            unsigned long long add = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < ntiles) tile_offsets[i] = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count_out = (long long)carry;
+}
+
+// mask_loader.py:675-679 / :706-709: flat[mask] (or flat[~mask]) for n_src buffers sharing one mask
+__global__ __launch_bounds__(ELT_THREADS) void k_mask_scatter(const float *const *__restrict__ src,
+                                                              float *const *__restrict__ dst, int n_src,
+                                                              const uint8_t *__restrict__ mask, int invert,
+                                                              int64_t numel,
+                                                              const unsigned long long *__restrict__ tile_offsets) {
+    const int64_t base = (int64_t)blockIdx.x * MASK_TILE + (int64_t)threadIdx.x * 8;
+    unsigned sel = 0, cnt = 0;
+    for (int e = 0; e < 8; ++e)
+        if (base + e < numel && ((mask[base + e] != 0) != (invert != 0))) {
+            sel |= 1u << e;
+            ++cnt;
+        }
+    __shared__ unsigned s[ELT_THREADS];
+    s[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 1; off < ELT_THREADS; off <<= 1) {
+        unsigned add = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (!cnt) return;
+    const unsigned long long pos0 = tile_offsets[blockIdx.x] + (s[threadIdx.x] - cnt);
+    for (int m = 0; m < n_src; ++m) {
+        const float *sp = src[m] + base;
+        float *dp = dst[m] + pos0;
+        unsigned j = 0;
+        for (int e = 0; e < 8; ++e)
+            if (sel & (1u << e)) dp[j++] = sp[e];
+    }
+}
+
+extern "C" int64_t svdq_mask_work_bytes(int64_t numel) {
+    const int64_t ntiles = (numel + MASK_TILE - 1) / MASK_TILE;
+    return svdq_align_up(ntiles * 4, 256) + svdq_align_up(ntiles * 8, 256) + 256;
+}
+
+extern "C" int svdq_mask_combine(const void *mask_ptrs, int32_t n_masks, int64_t numel, int32_t strategy, uint8_t *out,
+                                 int64_t *count, void *work, void *stream) {
+    (void)work;
+    if (n_masks < 1) {
+        svdq_set_error("Empty mask list");  // mask_loader.py:425
+        return SVDQ_EINVAL;
+    }
+    if (strategy < SVDQ_MASK_UNION || strategy > SVDQ_MASK_MAJORITY) {
+        svdq_set_error("Unknown mask strategy: %d", strategy);  // mask_loader.py:611
+        return SVDQ_EINVAL;
+    }
+    if (!mask_ptrs || !out || !count || numel < 1) {
+        svdq_set_error("svdq_mask_combine: bad argument");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(count, 0, 8, st) != hipSuccess) return SVDQ_EHIP;
+    const int ntiles = (int)((numel + MASK_TILE - 1) / MASK_TILE);
+    hipLaunchKernelGGL(k_mask_combine, dim3(ntiles), dim3(ELT_THREADS), 0, st,
+                       reinterpret_cast<const uint8_t *const *>(mask_ptrs), n_masks, numel, strategy, out,
+                       reinterpret_cast<unsigned long long *>(count));
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+extern "C" int svdq_mask_compact(const void *src_ptrs, const void *dst_ptrs, int32_t n_src, const uint8_t *mask,
+                                 int32_t invert, int64_t numel, int64_t *count, void *work, void *stream) {
+    if (!src_ptrs || !dst_ptrs || !mask || !count || !work || n_src < 1 || numel < 1) {
+        svdq_set_error("svdq_mask_compact: bad argument");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int ntiles = (int)((numel + MASK_TILE - 1) / MASK_TILE);
+    uint8_t *wb = reinterpret_cast<uint8_t *>(work);
+    unsigned *tile_counts = reinterpret_cast<unsigned *>(wb);
+    unsigned long long *tile_offsets = reinterpret_cast<unsigned long long *>(wb + svdq_align_up((int64_t)ntiles * 4, 256));
+    hipLaunchKernelGGL(k_mask_count, dim3(ntiles), dim3(ELT_THREADS), 0, st, mask, invert, numel, tile_counts);
+    hipLaunchKernelGGL(k_mask_scan, dim3(1), dim3(1024), 0, st, tile_counts, ntiles, tile_offsets,
+                       reinterpret_cast<long long *>(count));
+    hipLaunchKernelGGL(k_mask_scatter, dim3(ntiles), dim3(ELT_THREADS), 0, st,
+                       reinterpret_cast<const float *const *>(src_ptrs), reinterpret_cast<float *const *>(dst_ptrs),
+                       n_src, mask, invert, numel, tile_offsets);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+// ------------------------------------------------------------------------------------ projection
+// project_to_basis (compress.py:6-21) with the mean subtraction of compress.py:35-37 folded in,
+// for callers that bring their own basis: c[i] = sum_d float(U[d][i]) * (delta[d] - mean[d]).
+// Thread per row (adjacent threads read adjacent rows of the row-major [D,k] / [D,nl] arrays),
+// fp32 per thread, fp64 across threads and blocks, fixed-order final sum => deterministic.
+#define PROJ_BLOCKS 1024
+
+__device__ __forceinline__ float u_load(const __half *u, int64_t i) { return __half2float(u[i]); }
+__device__ __forceinline__ float u_load(const float *u, int64_t i) { return u[i]; }
+
+template <typename T>
+__global__ __launch_bounds__(ELT_THREADS) void k_project(const T *__restrict__ uh, const T *__restrict__ ul,
+                                                         int64_t rows, int k, int nl,
+                                                         const float *__restrict__ delta,
+                                                         const float *__restrict__ mean,
+                                                         double *__restrict__ part /*[grid][32]*/) {
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * ELT_THREADS;
+    for (int64_t d = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x; d < rows; d += stride) {
+        float x = delta[d];
+        if (mean) x = __fsub_rn(x, mean[d]);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i < k)
+                acc[i] = fmaf(u_load(uh, d * k + i), x, acc[i]);
+            else if (i < k + nl)
+                acc[i] = fmaf(u_load(ul, d * nl + (i - k)), x, acc[i]);
+        }
+    }
+    __shared__ double red[ELT_THREADS];
+    for (int i = 0; i < k + nl; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j == i) v = (double)acc[j];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
+            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * 32 + i] = red[0];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_project_finish(const double *__restrict__ part, int nblk, int ncols,
+                                                       float *__restrict__ c_out) {
+    const int i = threadIdx.x;
+    if (i >= ncols) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * 32 + i];
+    c_out[i] = (float)s;
+}
+
+static int project_grid(int64_t rows) {
+    int64_t b = (rows + ELT_THREADS * 8 - 1) / (ELT_THREADS * 8);
+    if (b < 1) b = 1;
+    if (b > PROJ_BLOCKS) b = PROJ_BLOCKS;
+    return (int)b;
+}
+
+extern "C" int64_t svdq_project_work_bytes(int64_t rows, int32_t ncols) {
+    (void)ncols;
+    return (int64_t)project_grid(rows) * 32 * 8 + 256;
+}
+
+extern "C" int svdq_project(const void *u_high, const void *u_low, int32_t u_fp16, int64_t rows, int32_t k, int32_t nl,
+                            const float *delta, const float *mean, float *c_out, void *work, void *stream) {
+    if (rows < 1 || k < 0 || nl < 0 || k + nl < 1 || k + nl > 32 || !delta || !c_out || !work ||
+        (k > 0 && !u_high) || (nl > 0 && !u_low)) {
+        svdq_set_error("svdq_project: bad argument (1 <= k + nl <= 32)");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = project_grid(rows);
+    double *part = reinterpret_cast<double *>(work);
+    if (u_fp16)
+        hipLaunchKernelGGL((k_project<__half>), dim3(grid), dim3(ELT_THREADS), 0, st,
+                           reinterpret_cast<const __half *>(u_high), reinterpret_cast<const __half *>(u_low), rows, k,
+                           nl, delta, mean, part);
+    else
+        hipLaunchKernelGGL((k_project<float>), dim3(grid), dim3(ELT_THREADS), 0, st,
+                           reinterpret_cast<const float *>(u_high), reinterpret_cast<const float *>(u_low), rows, k, nl,
+                           delta, mean, part);
+    hipLaunchKernelGGL(k_project_finish, dim3(1), dim3(64), 0, st, part, grid, k + nl, c_out);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}

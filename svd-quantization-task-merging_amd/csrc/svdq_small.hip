@@ -1,0 +1,295 @@
+// svdq_small.hip -- the two latency-bound kernels between / after the streaming passes.
+// Compiled with -ffp-contract=off: the quantizer must round scale*x and +zero_point separately.
+//
+//   k_eig    per parameter: deterministic fp64 reduction of the Gram partials, cyclic Jacobi
+//            eigen-solve of the N x N Gram in fp64, sigma = sqrt(lambda), the reference's fp32
+//            energy / rank rule (basis.py:116-156, 159-213, :367), W = V Sigma^-1.
+//   k_coeff  per parameter: deterministic fp64 reduction of the projection partials,
+//            c_high -> fp16 (compress.py:44-47), multi-stage affine quantization of c_low
+//            (rtvq.py:4-82) -- one lane per task, n = r-k <= 31 scalars each.
+
+#include "svdq_common.h"
+#include <hip/hip_fp16.h>
+
+#define EIG_THREADS 256
+#define LDN 33  // padded leading dimension of the N x N LDS matrices (N <= 32)
+
+// Sum partial matrices [slot][nn] over slots [s0, s1) into out[nn] (LDS), fixed order:
+// wave w takes slots s0+w, s0+w+4, ... ; the four wave sums are then added 0+1+2+3.
+__device__ void reduce_partials(const double *__restrict__ part, int s0, int s1, int nn, double *red /*[4][1024]*/,
+                                double *out /*[nn]*/) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    for (int e = l; e < nn; e += 64) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int s = s0 + w;
+        for (; s + 12 < s1; s += 16) {
+            a0 += part[(size_t)s * nn + e];
+            a1 += part[(size_t)(s + 4) * nn + e];
+            a2 += part[(size_t)(s + 8) * nn + e];
+            a3 += part[(size_t)(s + 12) * nn + e];
+        }
+        for (; s < s1; s += 4) a0 += part[(size_t)s * nn + e];
+        red[w * 1024 + e] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    for (int e = tid; e < nn; e += EIG_THREADS)
+        out[e] = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict__ params,
+                                                     const int64_t *__restrict__ rows_dev, int NT, int pack,
+                                                     float thr, int max_rank, const double *__restrict__ gram_part,
+                                                     float *__restrict__ Wtab, float *__restrict__ sigma_out,
+                                                     int32_t *__restrict__ k_out, int32_t *__restrict__ r_out,
+                                                     float *__restrict__ energy_out, int64_t *__restrict__ rows_out) {
+    __shared__ double red[4 * 1024];
+    __shared__ double G[1024];
+    __shared__ double A[32 * LDN];
+    __shared__ double V[32 * LDN];
+    __shared__ double lam[32];
+    __shared__ double rowoff[32];
+    __shared__ int order[32];
+    __shared__ double sgn[32];
+    __shared__ double sig[32];
+    __shared__ int done;
+
+    const int p = blockIdx.x, tid = threadIdx.x, n = NT;
+    const SvdqParam pd = params[p];
+    const int64_t D = rows_dev ? rows_dev[p] : pd.rows;
+    reduce_partials(gram_part, pd.unit_begin * pack, (pd.unit_begin + pd.unit_count) * pack, n * n, red, G);
+
+    for (int e = tid; e < n * n; e += EIG_THREADS) {
+        const int i = e / n, j = e % n;
+        // G is symmetric by construction (same products, same order); average anyway.
+        A[i * LDN + j] = 0.5 * (G[i * n + j] + G[j * n + i]);
+        V[i * LDN + j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        if (tid < n) {
+            double off = 0.0;
+            for (int j = 0; j < n; ++j)
+                if (j != tid) off += A[tid * LDN + j] * A[tid * LDN + j];
+            rowoff[tid] = off;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double off = 0.0, dg = 0.0;
+            for (int j = 0; j < n; ++j) {
+                off += rowoff[j];
+                dg += A[j * LDN + j] * A[j * LDN + j];
+            }
+            done = (off <= 1e-32 * dg) || (dg == 0.0);
+        }
+        __syncthreads();
+        if (done) break;
+        for (int pp = 0; pp < n - 1; ++pp) {
+            for (int q = pp + 1; q < n; ++q) {
+                const double app = A[pp * LDN + pp], aqq = A[q * LDN + q], apq = A[pp * LDN + q];
+                double ajp = 0.0, ajq = 0.0, vjp = 0.0, vjq = 0.0;
+                if (tid < n) {
+                    ajp = A[tid * LDN + pp];
+                    ajq = A[tid * LDN + q];
+                    vjp = V[tid * LDN + pp];
+                    vjq = V[tid * LDN + q];
+                }
+                __syncthreads();
+                if (apq != 0.0) {
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    const double cs = 1.0 / sqrt(1.0 + t * t);
+                    const double sn = t * cs;
+                    if (tid < n) {
+                        if (tid != pp && tid != q) {
+                            const double np_ = cs * ajp - sn * ajq;
+                            const double nq_ = sn * ajp + cs * ajq;
+                            A[tid * LDN + pp] = np_;
+                            A[pp * LDN + tid] = np_;
+                            A[tid * LDN + q] = nq_;
+                            A[q * LDN + tid] = nq_;
+                        }
+                        V[tid * LDN + pp] = cs * vjp - sn * vjq;
+                        V[tid * LDN + q] = sn * vjp + cs * vjq;
+                        if (tid == pp) {
+                            A[pp * LDN + pp] = app - t * apq;
+                            A[q * LDN + q] = aqq + t * apq;
+                            A[pp * LDN + q] = 0.0;
+                            A[q * LDN + pp] = 0.0;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // sort descending (stable on ties), sign convention: largest-|v| component positive
+    if (tid < n) lam[tid] = A[tid * LDN + tid];
+    __syncthreads();
+    if (tid < n) {
+        int rank = 0;
+        for (int i = 0; i < n; ++i)
+            if (lam[i] > lam[tid] || (lam[i] == lam[tid] && i < tid)) ++rank;
+        order[rank] = tid;
+    }
+    __syncthreads();
+    if (tid < n) {
+        const int col = order[tid];
+        const double l = lam[col];
+        sig[tid] = l > 0.0 ? sqrt(l) : 0.0;
+        double best = 0.0, bv = 1.0;
+        for (int j = 0; j < n; ++j) {
+            const double x = V[j * LDN + col];
+            if (fabs(x) > best) {
+                best = fabs(x);
+                bv = x;
+            }
+        }
+        sgn[tid] = bv < 0.0 ? -1.0 : 1.0;
+    }
+    __syncthreads();
+
+    const int r = (int)(D < (int64_t)n ? D : (int64_t)n);
+    if (tid == 0) {
+        // basis.py:147-156 and :199-211, fp32 like the reference (threshold compared as fp32)
+        float S[32], cum[32];
+        float total = 0.f;
+        for (int i = 0; i < r; ++i) {
+            S[i] = (float)sig[i];
+            total += S[i] * S[i];
+        }
+        if (total < 1e-10f) {
+            for (int i = 0; i < r; ++i) cum[i] = 1.f;
+        } else {
+            float run = 0.f;
+            for (int i = 0; i < r; ++i) {
+                run += S[i] * S[i];
+                cum[i] = run / total;
+            }
+        }
+        int kk = 1;
+        for (int i = 0; i < r; ++i)
+            if (cum[i] < thr) ++kk;
+        if (kk < 1) kk = 1;
+        if (max_rank > 0 && kk > max_rank) kk = max_rank;
+        if (kk > r) kk = r;
+        for (int i = 0; i < n; ++i) sigma_out[(size_t)p * n + i] = (i < r) ? S[i] : 0.f;
+        k_out[p] = kk;
+        r_out[p] = r;
+        energy_out[p] = (kk > 0 && r > 0) ? cum[kk - 1] : 0.f;
+        rows_out[p] = D;
+    }
+    // W[t][i] = sgn_i V[t][order[i]] / sigma_i ; directions below fp32 resolution of the data
+    // (sigma_i <= 1e-6 sigma_0, e.g. the null direction created by centring) are emitted as zero
+    // columns -- LAPACK returns an arbitrary unit vector there ("null directions").
+    const double s0 = sig[0];
+    for (int e = tid; e < n * n; e += EIG_THREADS) {
+        const int t = e / n, i = e % n;
+        double wv = 0.0;
+        if (i < r && sig[i] > 1e-6 * s0 && sig[i] > 0.0) wv = sgn[i] * V[t * LDN + order[i]] / sig[i];
+        Wtab[(size_t)p * n * n + e] = (float)wv;
+    }
+}
+
+// ------------------------------------------------------------------------------------ epilogue
+__device__ __forceinline__ float f_min_nan(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
+__device__ __forceinline__ float f_max_nan(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b > a ? b : a)); }
+
+__global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restrict__ params, int NT, int pack,
+                                                       int bits, int stages, const double *__restrict__ cpart,
+                                                       const int32_t *__restrict__ k_in,
+                                                       const int32_t *__restrict__ r_in,
+                                                       float *__restrict__ coef_out, uint16_t *__restrict__ chigh_out,
+                                                       uint8_t *__restrict__ codes_out, float *__restrict__ scale_out,
+                                                       float *__restrict__ zp_out, float *__restrict__ rnorm_out) {
+    __shared__ double red[4 * 1024];
+    __shared__ double C[1024];
+    __shared__ float res[32 * LDN];
+
+    const int p = blockIdx.x, tid = threadIdx.x, n = NT;
+    const SvdqParam pd = params[p];
+    reduce_partials(cpart, pd.unit_begin * pack, (pd.unit_begin + pd.unit_count) * pack, n * n, red, C);
+
+    const int k = k_in[p], r = r_in[p];
+    const int nl = r - k;
+    // c[t][i] fp32, c_high fp16 (round-to-nearest-even), zero padding past the valid prefix
+    for (int e = tid; e < n * n; e += EIG_THREADS) {
+        const int t = e / n, i = e % n;
+        const float cv = (float)C[e];
+        coef_out[(size_t)p * n * n + e] = cv;
+        chigh_out[(size_t)p * n * n + e] = (i < k) ? __half_as_ushort(__float2half_rn(cv)) : (uint16_t)0;
+        if (i >= k && i < r) res[t * LDN + (i - k)] = cv;
+    }
+    __syncthreads();
+
+    if (tid < n) {
+        const int t = tid;
+        float *x = res + t * LDN;
+        const float qmax = (float)((1 << bits) - 1);
+        const size_t sbase = ((size_t)p * n + t) * stages;
+        for (int s = 0; s < stages; ++s) {
+            uint8_t *cdst = codes_out + (sbase + s) * n;
+            if (nl <= 0) {
+                for (int j = 0; j < n; ++j) cdst[j] = 0;
+                scale_out[sbase + s] = 0.f;
+                zp_out[sbase + s] = 0.f;
+                rnorm_out[sbase + s] = 0.f;
+                continue;
+            }
+            double ss = 0.0;
+            float mn = x[0], mx = x[0];
+            for (int j = 0; j < nl; ++j) {
+                ss += (double)x[j] * (double)x[j];
+                mn = f_min_nan(mn, x[j]);
+                mx = f_max_nan(mx, x[j]);
+            }
+            // rtvq.py:17-18: python-int / Tensor == Tensor.reciprocal() * int -> two roundings
+            const float range = __fsub_rn(mx, mn);
+            const float recip = __fdiv_rn(1.0f, range);
+            const float scale = __fmul_rn(recip, qmax);
+            const float zp = __fmul_rn(-1.0f, rintf(__fmul_rn(scale, mn)));
+            for (int j = 0; j < nl; ++j) {
+                float vq = rintf(__fadd_rn(__fmul_rn(scale, x[j]), zp));
+                uint8_t q;
+                if (vq != vq) {
+                    q = 0;
+                } else {
+                    vq = vq < 0.f ? 0.f : (vq > qmax ? qmax : vq);
+                    q = (uint8_t)vq;
+                }
+                cdst[j] = q;
+                const float deq = __fdiv_rn(__fsub_rn((float)q, zp), scale);
+                x[j] = __fsub_rn(x[j], deq);
+            }
+            for (int j = nl; j < n; ++j) cdst[j] = 0;
+            scale_out[sbase + s] = scale;
+            zp_out[sbase + s] = zp;
+            rnorm_out[sbase + s] = (float)sqrt(ss);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+int svdq_launch_eig(const svdq_plan *pl, const int64_t *rows_dev, const double *gram_part, float *W, uint8_t *small,
+                    hipStream_t st) {
+    const svdq_small_layout &L = pl->small;
+    hipLaunchKernelGGL(k_eig, dim3(pl->n_params), dim3(EIG_THREADS), 0, st, pl->d_params, rows_dev, pl->n_tasks,
+                       pl->pack, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part, W,
+                       reinterpret_cast<float *>(small + L.sigma_off), reinterpret_cast<int32_t *>(small + L.k_off),
+                       reinterpret_cast<int32_t *>(small + L.r_off), reinterpret_cast<float *>(small + L.energy_off),
+                       reinterpret_cast<int64_t *>(small + L.rows_off));
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, uint8_t *small, hipStream_t st) {
+    const svdq_small_layout &L = pl->small;
+    hipLaunchKernelGGL(k_coeff, dim3(pl->n_params), dim3(EIG_THREADS), 0, st, pl->d_params, pl->n_tasks, pl->pack,
+                       pl->cfg.low_bits, pl->cfg.rtvq_stages, cpart, reinterpret_cast<const int32_t *>(small + L.k_off),
+                       reinterpret_cast<const int32_t *>(small + L.r_off), reinterpret_cast<float *>(small + L.coef_off),
+                       reinterpret_cast<uint16_t *>(small + L.chigh_off), small + L.codes_off,
+                       reinterpret_cast<float *>(small + L.scale_off), reinterpret_cast<float *>(small + L.zp_off),
+                       reinterpret_cast<float *>(small + L.rnorm_off));
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}

@@ -1,0 +1,490 @@
+// svdq_stream.hip -- the two HBM-streaming passes of the SVD-Hybrid compressor (gfx950 / CDNA4).
+//
+//   k_gram          pass 1: G = Tc^T Tc          (reference basis.py:63-113 + the reduction half of
+//                                                  torch.linalg.svd, basis.py:216-249)
+//   k_basis_project pass 2: U = Tc W -> fp16, mean, c = fp16(U)^T Tc
+//                                                 (basis.py:363-364, cli.py:354-361, compress.py:6-21,35-40)
+//
+// Both walk the same 256-row blocks.  One wavefront (= one 64-thread workgroup, so LDS is
+// wave-private and no cross-wave barrier exists) owns a unit of consecutive blocks:
+//
+//   global --16 B/lane, 1 KiB contiguous per task per instruction--> VGPR (next block prefetched)
+//          --row mean over tasks, subtract--> LDS  X[task][row]  (centred, zero past the end)
+//          --ds_read in the two MFMA operand layouts--> v_mfma_f32_16x16x4_f32
+//
+// MFMA operand layouts (16x16x4 f32: lane l supplies A[l&15][l>>4] and B[l>>4][l&15],
+// holds D[4*(l>>4)+reg][l&15]):
+//   "task on slot, row on k"  value X[task l&15][row 4*(l>>4)+e]   one ds_read_b128 = 4 MFMA steps
+//        Gram:        D[m][n] += X[m][row] * X[n][row]   (A and B are the SAME register)
+//        projection:  B operand; A operand is the rounded U tile straight out of the U-MFMA
+//                     accumulator (its D layout is exactly "U column on slot, row on k").
+//   "row on slot, task on k"  value X[task 4s+(l>>4)][row l&15]    ds_read_b32 per k-step s
+//        U = Tc W:    A operand; B operand W[4s+(l>>4)][l&15] lives in registers.
+//   Row-set packing (N <= 8): slots 0-7 carry tasks for one 16-row set, slots 8-15 the same tasks
+//   for the next 16 rows; the two diagonal 8x8 blocks of D are two independent partial sums.
+//
+// Accumulation: fp32 inside a block (64 MFMA k-steps), fp64 across blocks and units.
+
+#include "svdq_common.h"
+#include <hip/hip_fp16.h>
+
+#define XS SVDQ_XS
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 zero4() {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return z;
+}
+
+// Issue the 16-B loads of one 256-row block: lane l takes rows rb+4l..rb+4l+3 of every task.
+// Full blocks take the unconditional path (no per-load branch, all loads in flight together);
+// only the last block of a parameter takes the guarded one.
+template <int NTP>
+__device__ __forceinline__ void load_block(f32x4 (&v)[NTP], const float *(&bp)[NTP], int64_t rb,
+                                           int64_t D, int lane) {
+    const int64_t r = rb + 4 * lane;
+    if (rb + SVDQ_BLK_ROWS <= D) {
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) v[t] = *reinterpret_cast<const f32x4 *>(bp[t] + r);
+    } else {
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+            f32x4 o = zero4();
+            if (r < D) o.x = bp[t][r];
+            if (r + 1 < D) o.y = bp[t][r + 1];
+            if (r + 2 < D) o.z = bp[t][r + 2];
+            if (r + 3 < D) o.w = bp[t][r + 3];
+            v[t] = o;
+        }
+    }
+}
+
+// Row mean over the NT real tasks (sum in task order, then one fp32 divide: basis.py:109),
+// subtract (basis.py:111), and park the centred strip in LDS.  Padded tasks are stored as 0.
+template <int NTP>
+__device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int center, float *X, int lane) {
+    f32x4 s = zero4();
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) {
+        f32x4 x = (t < NT) ? v[t] : zero4();
+        s += x;
+    }
+    f32x4 mean = zero4();
+    if (center) {
+        const float n = (float)NT;
+        mean.x = s.x / n;
+        mean.y = s.y / n;
+        mean.z = s.z / n;
+        mean.w = s.w / n;
+    }
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) {
+        f32x4 xc = (t < NT) ? (v[t] - mean) : zero4();
+        *reinterpret_cast<f32x4 *>(X + t * XS + 4 * lane) = xc;
+    }
+    return mean;
+}
+
+// ------------------------------------------------------------------------------------ pass 1
+template <int NTP>
+__global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ params,
+                                             const SvdqUnit *__restrict__ units,
+                                             const float *const *__restrict__ ptrs,
+                                             const int64_t *__restrict__ rows_dev, int NT, int center,
+                                             double *__restrict__ gram_part) {
+    constexpr int PACK = (NTP <= 8) ? 2 : 1;
+    constexpr int NB = (NTP + 15) / 16;
+    constexpr int NACC = (NB == 1) ? 1 : 3;  // AA | AA, AB, BB
+    __shared__ __attribute__((aligned(16))) float X[NTP * XS];
+
+    const int lane = threadIdx.x;
+    const SvdqUnit ud = units[blockIdx.x];
+    const int p = ud.param;
+    const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
+    const int64_t r_begin = ud.row0;
+    int64_t r_end = r_begin + ud.nrows;
+    if (r_end > D) r_end = D;
+
+    const float *bp[NTP];
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) bp[t] = ptrs[(size_t)p * NT + (t < NT ? t : NT - 1)];
+
+    const int c = lane & 15, g = lane >> 4;
+    double accd[NACC][4];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accd[i][e] = 0.0;
+
+    f32x4 v[NTP];
+    if (r_begin < r_end) load_block<NTP>(v, bp, r_begin, D, lane);
+
+    for (int64_t rb = r_begin; rb < r_end; rb += SVDQ_BLK_ROWS) {
+        center_store<NTP>(v, NT, center, X, lane);
+        __syncthreads();
+        if (rb + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v, bp, rb + SVDQ_BLK_ROWS, D, lane);
+
+        f32x4 acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = zero4();
+
+        if constexpr (PACK == 2) {
+            const int t = c & 7;
+            const bool valid = t < NTP;
+            const float *xr = X + (valid ? t : 0) * XS + 16 * (c >> 3) + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 32 * j);
+                if (!valid) a = zero4();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0] = mfma4(a[e], a[e], acc[0]);
+            }
+        } else {
+            const bool v0 = c < NTP;
+            const bool v1 = (NB == 2) && (16 + c < NTP);
+            const float *x0 = X + (v0 ? c : 0) * XS + 4 * g;
+            const float *x1 = X + (v1 ? 16 + c : 0) * XS + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                f32x4 a0 = *reinterpret_cast<const f32x4 *>(x0 + 16 * j);
+                if (!v0) a0 = zero4();
+                if constexpr (NB == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[0] = mfma4(a0[e], a0[e], acc[0]);
+                } else {
+                    f32x4 a1 = *reinterpret_cast<const f32x4 *>(x1 + 16 * j);
+                    if (!v1) a1 = zero4();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = mfma4(a0[e], a0[e], acc[0]);
+                        acc[1] = mfma4(a0[e], a1[e], acc[1]);
+                        acc[2] = mfma4(a1[e], a1[e], acc[2]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accd[i][e] += (double)acc[i][e];
+        __syncthreads();
+    }
+
+    // One fp64 partial per slot, dense [NT][NT].  Lane (c,g) holds D[4g+e][c].
+    const int NN = NT * NT;
+    if constexpr (PACK == 2) {
+        const int rs = c >> 3, n = c & 7;
+        double *dst = gram_part + ((size_t)blockIdx.x * 2 + rs) * NN;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * g + e;
+            if ((m >> 3) == rs && (m & 7) < NT && n < NT) dst[(m & 7) * NT + n] = accd[0][e];
+        }
+    } else {
+        double *dst = gram_part + (size_t)blockIdx.x * NN;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * g + e;
+            if (m < NT && c < NT) dst[m * NT + c] = accd[0][e];
+            if constexpr (NB == 2) {
+                if (m < NT && 16 + c < NT) {
+                    dst[m * NT + 16 + c] = accd[1][e];
+                    dst[(16 + c) * NT + m] = accd[1][e];
+                }
+                if (16 + m < NT && 16 + c < NT) dst[(16 + m) * NT + 16 + c] = accd[2][e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ pass 2
+__device__ __forceinline__ void copy_out(const void *lds_src, uint8_t *gdst, int nbytes, int lane) {
+    const int nvec = nbytes >> 4;
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(lds_src);
+    f32x4 *d4 = reinterpret_cast<f32x4 *>(gdst);
+    for (int i = lane; i < nvec; i += 64) d4[i] = s4[i];
+    const uint8_t *sb = reinterpret_cast<const uint8_t *>(lds_src);
+    for (int b = (nvec << 4) + 2 * lane; b < nbytes; b += 128)
+        *reinterpret_cast<uint16_t *>(gdst + b) = *reinterpret_cast<const uint16_t *>(sb + b);
+}
+
+template <bool OUT16> struct OutT;
+template <> struct OutT<true> { using type = __half; };
+template <> struct OutT<false> { using type = float; };
+
+template <int NTP, bool OUT16>
+__global__ __launch_bounds__(64) void k_basis_project(
+    const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
+    const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
+    const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
+    uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart) {
+    constexpr int PACK = (NTP <= 8) ? 2 : 1;
+    constexpr int NB = (NTP + 15) / 16;
+    constexpr int KS = NTP / 4;
+    constexpr int NCB = NB * NB;
+    constexpr int ES = OUT16 ? 2 : 4;
+    using out_t = typename OutT<OUT16>::type;
+
+    __shared__ __attribute__((aligned(16))) float X[NTP * XS];
+    __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP];
+
+    const int lane = threadIdx.x;
+    const SvdqUnit ud = units[blockIdx.x];
+    const int p = ud.param;
+    const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
+    const int64_t r_begin = ud.row0;
+    int64_t r_end = r_begin + ud.nrows;
+    if (r_end > D) r_end = D;
+
+    const int k = k_dev[p];
+    const int r = r_dev[p];
+    const int nl = r - k;
+
+    const float *bp[NTP];
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) bp[t] = ptrs[(size_t)p * NT + (t < NT ? t : NT - 1)];
+
+    const int c = lane & 15, g = lane >> 4;
+
+    // W = V Sigma^-1 (columns >= r and null directions are already zero), B-operand registers.
+    const float *Wp = Wtab + (size_t)p * NT * NT;
+    float w[KS][NB];
+    float whi[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t = 4 * s + g;
+        if constexpr (PACK == 2) {
+            const int i = c & 7;
+            const float val = (t < NT && i < NT) ? Wp[t * NT + i] : 0.f;
+            w[s][0] = (c < 8) ? val : 0.f;
+            whi[s] = (c >= 8) ? val : 0.f;
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int i = 16 * nb + c;
+                w[s][nb] = (t < NT && i < NT) ? Wp[t * NT + i] : 0.f;
+            }
+            whi[s] = 0.f;
+        }
+    }
+
+    out_t *OUTh = OUT;
+    out_t *OUTl = OUT + SVDQ_BLK_ROWS * k;
+    uint8_t *slab = basis + params[p].slab_off;
+    uint8_t *gUh = slab;
+    uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
+    float *gmean = (center && meanbuf) ? meanbuf + params[p].mean_off : nullptr;
+
+    double caccd[NCB][4];
+#pragma unroll
+    for (int i = 0; i < NCB; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) caccd[i][e] = 0.0;
+
+    f32x4 v[NTP];
+    if (r_begin < r_end) load_block<NTP>(v, bp, r_begin, D, lane);
+
+    for (int64_t rb = r_begin; rb < r_end; rb += SVDQ_BLK_ROWS) {
+        const f32x4 mean = center_store<NTP>(v, NT, center, X, lane);
+        if (gmean) {
+            const int64_t rr = rb + 4 * lane;
+            if (rr + 3 < D) {
+                *reinterpret_cast<f32x4 *>(gmean + rr) = mean;
+            } else {
+                if (rr < D) gmean[rr] = mean.x;
+                if (rr + 1 < D) gmean[rr + 1] = mean.y;
+                if (rr + 2 < D) gmean[rr + 2] = mean.z;
+            }
+        }
+        __syncthreads();
+        if (rb + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v, bp, rb + SVDQ_BLK_ROWS, D, lane);
+
+        f32x4 cf[NCB];
+#pragma unroll
+        for (int i = 0; i < NCB; ++i) cf[i] = zero4();
+
+        if constexpr (PACK == 2) {
+            const int i = c & 7;
+            const bool bvalid = i < NTP;
+            const float *xb = X + (bvalid ? i : 0) * XS + 16 * (c >> 3) + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x4 u = zero4();
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const float a0 = X[(4 * s + g) * XS + 32 * j + c];
+                    const float a1 = X[(4 * s + g) * XS + 32 * j + 16 + c];
+                    u = mfma4(a0, w[s][0], u);
+                    u = mfma4(a1, whi[s], u);
+                }
+                f32x4 uh;
+                const int row0 = 32 * j + 16 * (c >> 3) + 4 * g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    out_t h;
+                    if constexpr (OUT16) {
+                        h = __float2half_rn(u[e]);
+                        uh[e] = __half2float(h);
+                    } else {
+                        h = u[e];
+                        uh[e] = u[e];
+                    }
+                    if (i < k)
+                        OUTh[(row0 + e) * k + i] = h;
+                    else if (i < r)
+                        OUTl[(row0 + e) * nl + (i - k)] = h;
+                }
+                f32x4 b = *reinterpret_cast<const f32x4 *>(xb + 32 * j);
+                if (!bvalid) b = zero4();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cf[0] = mfma4(uh[e], b[e], cf[0]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                f32x4 u[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) u[nb] = zero4();
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const float a = X[(4 * s + g) * XS + 16 * j + c];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) u[nb] = mfma4(a, w[s][nb], u[nb]);
+                }
+                f32x4 uh[NB];
+                const int row0 = 16 * j + 4 * g;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int i = 16 * nb + c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        out_t h;
+                        if constexpr (OUT16) {
+                            h = __float2half_rn(u[nb][e]);
+                            uh[nb][e] = __half2float(h);
+                        } else {
+                            h = u[nb][e];
+                            uh[nb][e] = u[nb][e];
+                        }
+                        if (i < k)
+                            OUTh[(row0 + e) * k + i] = h;
+                        else if (i < r)
+                            OUTl[(row0 + e) * nl + (i - k)] = h;
+                    }
+                }
+                f32x4 b[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int t = 16 * nb + c;
+                    const bool bv = t < NTP;
+                    b[nb] = *reinterpret_cast<const f32x4 *>(X + (bv ? t : 0) * XS + 16 * j + 4 * g);
+                    if (!bv) b[nb] = zero4();
+                }
+#pragma unroll
+                for (int nbi = 0; nbi < NB; ++nbi)
+#pragma unroll
+                    for (int nbt = 0; nbt < NB; ++nbt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            cf[nbi * NB + nbt] = mfma4(uh[nbi][e], b[nbt][e], cf[nbi * NB + nbt]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCB; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) caccd[i][e] += (double)cf[i][e];
+        __syncthreads();
+
+        // stream the two row-major output tiles of this block out of LDS, 16 B per lane
+        const int rows_blk = (int)((D - rb < SVDQ_BLK_ROWS) ? (D - rb) : SVDQ_BLK_ROWS);
+        if (k > 0) copy_out(OUTh, gUh + rb * (int64_t)k * ES, rows_blk * k * ES, lane);
+        if (nl > 0) copy_out(OUTl, gUl + rb * (int64_t)nl * ES, rows_blk * nl * ES, lane);
+        __syncthreads();
+    }
+
+    // projection partials: cpart[slot][t*NT + i]; lane (c,g) holds D[m = U column][n = task]
+    const int NN = NT * NT;
+    if constexpr (PACK == 2) {
+        const int rs = c >> 3, t = c & 7;
+        double *dst = cpart + ((size_t)blockIdx.x * 2 + rs) * NN;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 4 * g + e;
+            if ((m >> 3) == rs && (m & 7) < NT && t < NT) dst[t * NT + (m & 7)] = caccd[0][e];
+        }
+    } else {
+        double *dst = cpart + (size_t)blockIdx.x * NN;
+#pragma unroll
+        for (int nbi = 0; nbi < NB; ++nbi)
+#pragma unroll
+            for (int nbt = 0; nbt < NB; ++nbt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 16 * nbi + 4 * g + e;
+                    const int t = 16 * nbt + c;
+                    if (i < NT && t < NT) dst[t * NT + i] = caccd[nbi * NB + nbt][e];
+                }
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+template <int NTP>
+static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(k_gram<NTP>, dim3(pl->n_units), dim3(64), 0, st, pl->d_params, pl->d_units,
+                       reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks, pl->cfg.center,
+                       gram_part);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
+                     hipStream_t st) {
+    switch (pl->ntp) {
+        case 4: return launch_gram_t<4>(pl, ptrs, rows_dev, gram_part, st);
+        case 8: return launch_gram_t<8>(pl, ptrs, rows_dev, gram_part, st);
+        case 12: return launch_gram_t<12>(pl, ptrs, rows_dev, gram_part, st);
+        case 16: return launch_gram_t<16>(pl, ptrs, rows_dev, gram_part, st);
+        case 20: return launch_gram_t<20>(pl, ptrs, rows_dev, gram_part, st);
+        case 24: return launch_gram_t<24>(pl, ptrs, rows_dev, gram_part, st);
+        case 28: return launch_gram_t<28>(pl, ptrs, rows_dev, gram_part, st);
+        case 32: return launch_gram_t<32>(pl, ptrs, rows_dev, gram_part, st);
+    }
+    svdq_set_error("unsupported padded task count %d", pl->ntp);
+    return SVDQ_EUNSUPPORTED;
+}
+
+template <int NTP>
+static int launch_bp_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
+                       const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
+                       hipStream_t st) {
+    auto pp = reinterpret_cast<const float *const *>(ptrs);
+    if (pl->cfg.fp16)
+        hipLaunchKernelGGL((k_basis_project<NTP, true>), dim3(pl->n_units), dim3(64), 0, st, pl->d_params,
+                           pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,
+                           cpart);
+    else
+        hipLaunchKernelGGL((k_basis_project<NTP, false>), dim3(pl->n_units), dim3(64), 0, st, pl->d_params,
+                           pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,
+                           cpart);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
+                              const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
+                              double *cpart, hipStream_t st) {
+    switch (pl->ntp) {
+        case 4: return launch_bp_t<4>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
+        case 8: return launch_bp_t<8>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
+        case 12: return launch_bp_t<12>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
+        case 16: return launch_bp_t<16>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
+        case 20: return launch_bp_t<20>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
+        case 24: return launch_bp_t<24>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
+        case 28: return launch_bp_t<28>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
+        case 32: return launch_bp_t<32>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
+    }
+    svdq_set_error("unsupported padded task count %d", pl->ntp);
+    return SVDQ_EUNSUPPORTED;
+}

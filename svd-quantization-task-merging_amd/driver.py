@@ -1,0 +1,129 @@
+"""
+Fused Step 4 + Step 5 driver (reference cli.py:311-361 and cli.py:436-442): every parameter of a
+model, masked and noise regions included, goes through ONE plan -- four kernel launches and one
+small D2H copy for the whole model -- and comes back as the reference's ``bases`` and
+``compressed_all`` dictionaries.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .pipeline import (BatchResult, CompressPlan, basis_dict, prepare_vector, resolve_device, task_artifact)
+from . import mask_loader as ml
+
+_BATCH_KEY = "_svdq_batch"
+
+
+def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks: Optional[Dict[str, torch.Tensor]],
+                config, device="cuda") -> Dict[str, Dict]:
+    """Step 4 for all parameters.  Returns ``bases`` (reference layout: {param: {"masked": basis|None,
+    "noise": basis|None}}), already cast to fp16 when ``config.svd_fp16`` (cli.py:354-361), with the
+    coefficients of Step 5 attached for ``compress_all_parameters``."""
+    dev = resolve_device(device)
+    combined_masks = combined_masks or {}
+    names = sorted({n for tv in task_vectors.values() for n in tv.keys()})
+    tasks = list(task_vectors.keys())
+    include_noise = bool(config.svd_include_noise)
+    min_size = int(config.svd_min_mask_size)
+
+    # group regions by the number of tasks that have the parameter (one plan per N)
+    groups: Dict[int, List[dict]] = {}
+    keep = []
+    with torch.cuda.device(dev):
+        for name in names:
+            present = [t for t in tasks if name in task_vectors[t]]
+            if not present:
+                continue
+            deltas = [task_vectors[t][name] for t in present]
+            mask = combined_masks.get(name)
+            if mask is not None and mask.shape == deltas[0].shape:
+                vs, cnt, ka = ml.compact(deltas, mask, invert=False)
+                keep.append(ka)
+                entry = {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": cnt,
+                         "upper": vs[0].numel(), "min": min_size}
+                groups.setdefault(len(present), []).append(entry)
+                if include_noise:
+                    vn, cn, kb = ml.compact(deltas, mask, invert=True)
+                    keep.append(kb)
+                    groups.setdefault(len(present), []).append(
+                        {"name": name, "region": "noise", "tasks": present, "vectors": vn, "count": cn,
+                         "upper": vn[0].numel(), "min": 1})
+            else:
+                vs = [prepare_vector(d, dev) for d in deltas]
+                if vs[0].numel() == 0:
+                    continue
+                groups.setdefault(len(present), []).append(
+                    {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": None,
+                     "upper": vs[0].numel(), "min": 0})
+
+        bases: Dict[str, Dict] = {}
+        for n_tasks, entries in groups.items():
+            entries = [e for e in entries if e["upper"] > 0]
+            if not entries:
+                continue
+            plan = CompressPlan([e["upper"] for e in entries], n_tasks,
+                                energy_threshold=config.svd_energy_threshold, max_rank=config.svd_max_rank,
+                                center=config.svd_center, fp16=config.svd_fp16, low_bits=config.svd_low_bits,
+                                rtvq_stages=config.svd_rtvq_stages, device=dev)
+            rows_dev = None
+            if any(e["count"] is not None for e in entries):
+                # rows actually processed = mask.sum() (device), or 0 when below svd_min_mask_size
+                parts = []
+                for e in entries:
+                    if e["count"] is None:
+                        parts.append(torch.tensor([e["upper"]], dtype=torch.int64, device=dev))
+                    else:
+                        c = e["count"]
+                        parts.append(torch.where(c >= e["min"], c, torch.zeros_like(c)))
+                rows_dev = torch.cat(parts)
+            table = plan.pointer_table([e["vectors"] for e in entries])
+            plan.run(table, rows_dev)
+            small = plan.fetch_small()
+            batch = BatchResult(plan, small, [(e["name"], e["region"]) for e in entries],
+                                [e["tasks"] for e in entries])
+            batch.keep = keep
+            for i, e in enumerate(entries):
+                slot = bases.setdefault(e["name"], {"masked": None, "noise": None})
+                if int(small.rows[i]) <= 0:
+                    continue
+                b = basis_dict(plan, small, i)
+                b[_BATCH_KEY] = (batch, i)
+                slot[e["region"]] = b
+    # parameters whose masked region was skipped (mask.sum() < svd_min_mask_size) have no basis
+    # entry at all in the reference (cli.py:343 guards the assignment)
+    return {n: b for n, b in bases.items() if b["masked"] is not None}
+
+
+def artifacts_from_batch(name: str, basis: Dict, task_vectors, config) -> Optional[Dict]:
+    """{task: {"masked": art|None, "unmasked": art|None}} from the fused run, or None if this basis
+    did not come from ``build_bases`` (then compress.py runs the per-task route)."""
+    bm = basis.get("masked")
+    if bm is None or _BATCH_KEY not in bm:
+        return None
+    batch, i = bm[_BATCH_KEY]
+    if (batch.plan.bits, batch.plan.S) != (config.svd_low_bits, config.svd_rtvq_stages):
+        return None
+    out = {}
+    tasks_i = batch.task_names[i]
+    bn = basis.get("noise") if config.svd_include_noise else None
+    for t in task_vectors.keys():
+        if name not in task_vectors[t]:
+            continue
+        art = {"masked": None, "unmasked": None}
+        if t in tasks_i:
+            art["masked"] = task_artifact(batch.plan, batch.small, i, tasks_i.index(t))
+        if bn is not None and _BATCH_KEY in bn:
+            nb, j = bn[_BATCH_KEY]
+            if t in nb.task_names[j]:
+                art["unmasked"] = task_artifact(nb.plan, nb.small, j, nb.task_names[j].index(t))
+        out[t] = art
+    return out
+
+
+def run_basis_and_compress(task_vectors, combined_masks, config, device="cuda") -> Tuple[Dict, Dict]:
+    """cli.py Step 4 + Step 5 in one call: (bases, compressed_all)."""
+    from .compress import compress_all_parameters
+    bases = build_bases(task_vectors, combined_masks, config, device)
+    return bases, compress_all_parameters(task_vectors, combined_masks or {}, bases, config, device)

@@ -1,0 +1,254 @@
+"""
+Batched driver of the HIP hot path: one plan = a ragged batch of parameter tensors x N tasks,
+four kernel launches for the whole batch, one D2H copy of the small artifacts.
+
+This is the body of the reference's Step 4 + Step 5 (cli.py:311-361 basis loop, cli.py:436-442
+-> compress.py:173-207), re-organised so that no host round trip happens between "task deltas
+resident in HBM" and "artifacts resident in HBM".  The per-call functions of basis.py /
+compress.py in this package are thin P=1 wrappers over the same plan.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_int64, c_void_p
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+def resolve_device(device) -> torch.device:
+    """``"cuda"`` strings keep working on ROCm; there is no CPU implementation to fall back to."""
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    if not torch.cuda.is_available():
+        raise RuntimeError("svdq_amd runs on an MI355X through libsvdq_hip.so; no GPU is visible "
+                           f"(requested device {device!r}) and there is no CPU fallback")
+    if dev.type != "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def prepare_vector(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
+    """fp32, contiguous, flat, on ``dev``, 16-byte aligned (the only input contract of the ABI)."""
+    v = t.detach()
+    if v.device != dev or v.dtype != torch.float32:
+        v = v.to(device=dev, dtype=torch.float32)
+    v = v.contiguous().view(-1)
+    if v.data_ptr() % 16 != 0:
+        v = v.clone()
+    return v
+
+
+def _stream_ptr() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> c_void_p:
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+@dataclass
+class SmallArtifacts:
+    """Host copy of the packed small-artifact buffer, as typed numpy views."""
+    sigma: np.ndarray      # [P, N] f32
+    k: np.ndarray          # [P] i32
+    r: np.ndarray          # [P] i32
+    energy: np.ndarray     # [P] f32
+    rows: np.ndarray       # [P] i64
+    c_high: np.ndarray     # [P, N, N] f16
+    codes: np.ndarray      # [P, N, S, N] u8
+    scale: np.ndarray      # [P, N, S] f32
+    zero_point: np.ndarray  # [P, N, S] f32
+    residual_norm: np.ndarray  # [P, N, S] f32
+    coef: np.ndarray       # [P, N, N] f32
+
+
+class CompressPlan:
+    """Owns one ``svdq_plan`` plus its device buffers (workspace, basis slabs, means, small)."""
+
+    def __init__(self, rows: Sequence[int], n_tasks: int, *, energy_threshold: float = 0.90,
+                 max_rank: Optional[int] = None, center: bool = True, fp16: bool = True,
+                 low_bits: int = 4, rtvq_stages: int = 2, device="cuda", unit_rows: int = 0):
+        self.lib = nat.lib()
+        self.device = resolve_device(device)
+        self.rows = [int(x) for x in rows]
+        self.P = len(self.rows)
+        self.N = int(n_tasks)
+        self.S = int(rtvq_stages)
+        self.bits = int(low_bits)
+        self.fp16 = bool(fp16)
+        self.center = bool(center)
+        self.cfg = nat.SvdqConfig(float(energy_threshold), int(max_rank) if max_rank else 0, int(bool(center)),
+                                  int(bool(fp16)), int(low_bits), int(rtvq_stages), int(unit_rows), 0)
+        self._h = c_void_p()
+        rows_arr = (c_int64 * max(self.P, 1))(*self.rows)
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_plan_create(byref(self._h), self.N, self.P, rows_arr, byref(self.cfg)),
+                      "svdq_plan_create")
+        self.sizes = nat.SvdqSizes()
+        nat.check(self.lib.svdq_plan_sizes(self._h, byref(self.sizes)), "svdq_plan_sizes")
+        self.layout = nat.SvdqSmallLayout()
+        nat.check(self.lib.svdq_plan_small_layout(self._h, byref(self.layout)), "svdq_plan_small_layout")
+        slab = (c_int64 * self.P)()
+        moff = (c_int64 * self.P)()
+        nat.check(self.lib.svdq_plan_basis_layout(self._h, slab, moff), "svdq_plan_basis_layout")
+        self.slab_off = list(slab)
+        self.mean_off = list(moff)
+        dev = self.device
+        self.workspace = torch.empty(self.sizes.workspace_bytes, dtype=torch.uint8, device=dev)
+        self.small = torch.zeros(self.sizes.small_bytes, dtype=torch.uint8, device=dev)
+        self.basis = torch.empty(self.sizes.basis_bytes, dtype=torch.uint8, device=dev)
+        self.mean = torch.empty(self.sizes.mean_floats, dtype=torch.float32, device=dev) if center else None
+        self._keep = None
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.svdq_plan_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs
+    def pointer_table(self, vectors: Sequence[Sequence[torch.Tensor]]) -> torch.Tensor:
+        """vectors[p][t] -> device int64 tensor [P*N] of data pointers (parameter-major)."""
+        assert len(vectors) == self.P
+        ptrs = []
+        for p, vs in enumerate(vectors):
+            if len(vs) != self.N:
+                raise ValueError(f"parameter {p}: expected {self.N} task vectors, got {len(vs)}")
+            for v in vs:
+                if v.dtype != torch.float32 or not v.is_contiguous() or v.device != self.device:
+                    raise ValueError("task vectors must be contiguous fp32 tensors on the plan's device")
+                if v.data_ptr() % 16 != 0:
+                    raise ValueError("task vector base address must be 16-byte aligned")
+                if v.numel() < self.rows[p]:
+                    raise ValueError(f"parameter {p}: vector has {v.numel()} elements, plan says {self.rows[p]}")
+                ptrs.append(v.data_ptr())
+        self._keep = vectors  # the table holds raw addresses: keep the owners alive
+        return torch.tensor(ptrs, dtype=torch.int64).to(self.device)
+
+    # ---- stages (all asynchronous on the current stream)
+    def gram_center(self, table, rows_dev=None):
+        nat.check(self.lib.svdq_gram_center(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace),
+                                            _stream_ptr()), "svdq_gram_center")
+
+    def eig_rank_select(self, rows_dev=None):
+        nat.check(self.lib.svdq_eig_rank_select(self._h, _ptr(rows_dev), _ptr(self.workspace), _ptr(self.small),
+                                                _stream_ptr()), "svdq_eig_rank_select")
+
+    def basis_project(self, table, rows_dev=None):
+        nat.check(self.lib.svdq_basis_project(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace),
+                                              _ptr(self.small), _ptr(self.basis), _ptr(self.mean), _stream_ptr()),
+                  "svdq_basis_project")
+
+    def coeff_quantize(self):
+        nat.check(self.lib.svdq_coeff_quantize(self._h, _ptr(self.workspace), _ptr(self.small), _stream_ptr()),
+                  "svdq_coeff_quantize")
+
+    def run(self, table, rows_dev=None):
+        """gram -> eig/rank -> basis+projection -> coefficient quantization, back to back."""
+        nat.check(self.lib.svdq_compress(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace), _ptr(self.small),
+                                         _ptr(self.basis), _ptr(self.mean), _stream_ptr()), "svdq_compress")
+
+    # ---- outputs
+    def fetch_small(self) -> SmallArtifacts:
+        host = self.small.cpu().numpy()  # the one D2H copy (synchronises the stream)
+        L, P, N, S = self.layout, self.P, self.N, self.S
+
+        def view(off, dtype, shape):
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return host[off:off + n].view(dtype).reshape(shape)
+
+        return SmallArtifacts(
+            sigma=view(L.sigma_off, np.float32, (P, N)), k=view(L.k_off, np.int32, (P,)),
+            r=view(L.r_off, np.int32, (P,)), energy=view(L.energy_off, np.float32, (P,)),
+            rows=view(L.rows_off, np.int64, (P,)), c_high=view(L.chigh_off, np.float16, (P, N, N)),
+            codes=view(L.codes_off, np.uint8, (P, N, S, N)), scale=view(L.scale_off, np.float32, (P, N, S)),
+            zero_point=view(L.zp_off, np.float32, (P, N, S)), residual_norm=view(L.rnorm_off, np.float32, (P, N, S)),
+            coef=view(L.coef_off, np.float32, (P, N, N)))
+
+    def basis_tensors(self, p: int, k: int, r: int, rows: int) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+        """Zero-copy views (U_high [rows,k], U_low [rows,r-k], mean [rows,1] | None) of parameter p."""
+        es = 2 if self.fp16 else 4
+        dt = torch.float16 if self.fp16 else torch.float32
+        base = self.slab_off[p]
+        hi_bytes = rows * k * es
+        lo_off = base + (hi_bytes + 255) // 256 * 256
+        nl = r - k
+        U_high = self.basis[base:base + hi_bytes].view(dt).view(rows, k)
+        if nl > 0:
+            U_low = self.basis[lo_off:lo_off + rows * nl * es].view(dt).view(rows, nl)
+        else:
+            U_low = torch.empty((rows, 0), dtype=dt, device=self.device)
+        mean = None
+        if self.center:
+            mean = self.mean[self.mean_off[p]:self.mean_off[p] + rows].view(rows, 1)
+        return U_high, U_low, mean
+
+
+# ------------------------------------------------------------------------------------------------
+def quant_payloads(sm: SmallArtifacts, p: int, t: int, nl: int, bits: int, stages: int) -> Dict:
+    """RTVQQuantizer.quantize output layout (reference rtvq.py:111-126, payloads rtvq.py:69-75)."""
+    payloads = []
+    if nl > 0:
+        for s in range(stages):
+            payloads.append({
+                "stage": s,
+                "quantized": torch.from_numpy(sm.codes[p, t, s, :nl].copy()),
+                "scale": torch.tensor(sm.scale[p, t, s]),
+                "zero_point": torch.tensor(sm.zero_point[p, t, s]),
+                "residual_norm": float(sm.residual_norm[p, t, s]),
+            })
+    return {"payloads": payloads, "num_bits": bits, "num_stages": stages,
+            "original_shape": torch.Size([nl]), "original_dtype": "torch.float32"}
+
+
+def basis_dict(plan: CompressPlan, sm: SmallArtifacts, p: int) -> Dict:
+    """construct_basis return layout (reference basis.py:398-407)."""
+    k, r, rows = int(sm.k[p]), int(sm.r[p]), int(sm.rows[p])
+    U_high, U_low, mean = plan.basis_tensors(p, k, r, rows)
+    S = torch.from_numpy(sm.sigma[p, :r].copy()).to(plan.device)
+    return {"U_high": U_high, "U_low": U_low, "singular_values": S, "k": k, "mean": mean,
+            "energy_retained": float(sm.energy[p]), "D": rows, "N": plan.N}
+
+
+def task_artifact(plan: CompressPlan, sm: SmallArtifacts, p: int, t: int) -> Dict:
+    """compress_single_task return layout (reference compress.py:53-56); CPU tensors."""
+    k, r = int(sm.k[p]), int(sm.r[p])
+    return {"c_high_fp16": torch.from_numpy(sm.c_high[p, t, :k].copy()),
+            "c_low_quant": quant_payloads(sm, p, t, r - k, plan.bits, plan.S)}
+
+
+class BatchResult:
+    """What one plan run produced, kept alive as long as any basis view is in use."""
+
+    def __init__(self, plan: CompressPlan, small: SmallArtifacts, entries: List[Tuple[str, str]],
+                 task_names: List[List[str]]):
+        self.plan, self.small, self.entries, self.task_names = plan, small, entries, task_names
+        self.index = {e: i for i, e in enumerate(entries)}
+
+
+def compress_batch(vectors: List[List[torch.Tensor]], *, energy_threshold: float, max_rank: Optional[int],
+                   center: bool, fp16: bool, low_bits: int, rtvq_stages: int, device,
+                   rows_dev: Optional[torch.Tensor] = None, rows_upper: Optional[List[int]] = None,
+                   unit_rows: int = 0) -> Tuple[CompressPlan, SmallArtifacts]:
+    """Run the four stages on vectors[p][t] (flat fp32 device tensors). Returns (plan, small)."""
+    dev = resolve_device(device)
+    rows = rows_upper if rows_upper is not None else [int(vs[0].numel()) for vs in vectors]
+    plan = CompressPlan(rows, len(vectors[0]), energy_threshold=energy_threshold, max_rank=max_rank, center=center,
+                        fp16=fp16, low_bits=low_bits, rtvq_stages=rtvq_stages, device=dev, unit_rows=unit_rows)
+    with torch.cuda.device(dev):
+        table = plan.pointer_table(vectors)
+        plan.run(table, rows_dev)
+        small = plan.fetch_small()
+    return plan, small
