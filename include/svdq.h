@@ -116,9 +116,11 @@ int svdq_gram_center(const svdq_plan *plan, const void *delta_ptrs_dev, const in
 /* ---- N x N eigen-solve + rank selection  (second half of compute_svd; compute_energy_spectrum
  *      basis.py:116-156; select_rank basis.py:159-213; energy_retained basis.py:367).
  *      Cyclic Jacobi in fp64, sigma = sqrt(lambda) -> fp32, fp32 cumsum rule of the reference.
- *      Writes sigma / k / r / energy / rows into small_dev and W = V Sigma^-1 into the workspace. */
-int svdq_eig_rank_select(const svdq_plan *plan, const int64_t *rows_dev, void *workspace_dev,
-                         void *small_dev, void *stream);
+ *      Writes sigma / k / r / energy / rows into small_dev and W = V Sigma^-1 into the workspace.
+ *      Reads row 0 of every task (delta_ptrs_dev) to build the orthonormal completion column of the
+ *      null direction that centring creates (LAPACK returns an arbitrary orthonormal vector there). */
+int svdq_eig_rank_select(const svdq_plan *plan, const void *delta_ptrs_dev, const int64_t *rows_dev,
+                         void *workspace_dev, void *small_dev, void *stream);
 
 /* ---- pass 2: basis + projection  (U = Tc W and the split of basis.py:363-364, the fp16 cast
  *      of cli.py:354-361, mean of basis.py:109, and project_to_basis compress.py:6-21 for all

@@ -48,7 +48,7 @@ SIGNATURES = {
     "svdq_plan_small_layout": (c_int32, [c_void_p, POINTER(SvdqSmallLayout)]),
     "svdq_plan_basis_layout": (c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     "svdq_gram_center": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "svdq_eig_rank_select": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_eig_rank_select": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_basis_project": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_coeff_quantize": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_compress": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -129,7 +129,7 @@ extern "C" int svdq_plan_create(svdq_plan **out, int32_t n_tasks, int32_t n_para
     pl->ws_cpart_off = off;
     off += svdq_align_up((int64_t)pl->n_slots * nn * 8, 256);
     pl->ws_w_off = off;
-    off += svdq_align_up((int64_t)n_params * nn * 4, 256);
+    off += svdq_align_up((int64_t)n_params * (nn + 4) * 4, 256);  // W [N][N] + {spike, null column, -, -}
     pl->sizes.workspace_bytes = off;
     pl->sizes.basis_bytes = basis_bytes;
     pl->sizes.mean_floats = mean_floats;
@@ -210,13 +210,13 @@ extern "C" int svdq_gram_center(const svdq_plan *pl, const void *ptrs, const int
                             (hipStream_t)stream);
 }
 
-extern "C" int svdq_eig_rank_select(const svdq_plan *pl, const int64_t *rows_dev, void *workspace, void *small,
-                                    void *stream) {
-    if (!pl || !workspace || !small) {
+extern "C" int svdq_eig_rank_select(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                                    void *small, void *stream) {
+    if (!pl || !ptrs || !workspace || !small) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
     }
-    return svdq_launch_eig(pl, rows_dev, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram_off)),
+    return svdq_launch_eig(pl, ptrs, rows_dev, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram_off)),
                            reinterpret_cast<float *>(ws(workspace, pl->ws_w_off)), reinterpret_cast<uint8_t *>(small),
                            (hipStream_t)stream);
 }
@@ -251,7 +251,7 @@ extern "C" int svdq_coeff_quantize(const svdq_plan *pl, void *workspace, void *s
 extern "C" int svdq_compress(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
                              void *small, void *basis, float *mean, void *stream) {
     int rc = svdq_gram_center(pl, ptrs, rows_dev, workspace, stream);
-    if (rc == SVDQ_OK) rc = svdq_eig_rank_select(pl, rows_dev, workspace, small, stream);
+    if (rc == SVDQ_OK) rc = svdq_eig_rank_select(pl, ptrs, rows_dev, workspace, small, stream);
     if (rc == SVDQ_OK) rc = svdq_basis_project(pl, ptrs, rows_dev, workspace, small, basis, mean, stream);
     if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
     return rc;

@@ -61,6 +61,6 @@ int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
                               double *cpart, hipStream_t st);
-int svdq_launch_eig(const svdq_plan *pl, const int64_t *rows_dev, const double *gram_part, float *W,
+int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W,
                     uint8_t *small, hipStream_t st);
 int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, uint8_t *small, hipStream_t st);

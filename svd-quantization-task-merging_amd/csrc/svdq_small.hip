@@ -38,8 +38,9 @@ __device__ void reduce_partials(const double *__restrict__ part, int s0, int s1,
 }
 
 __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict__ params,
+                                                     const float *const *__restrict__ ptrs,
                                                      const int64_t *__restrict__ rows_dev, int NT, int pack,
-                                                     float thr, int max_rank, const double *__restrict__ gram_part,
+                                                     int center, float thr, int max_rank, const double *__restrict__ gram_part,
                                                      float *__restrict__ Wtab, float *__restrict__ sigma_out,
                                                      int32_t *__restrict__ k_out, int32_t *__restrict__ r_out,
                                                      float *__restrict__ energy_out, int64_t *__restrict__ rows_out) {
@@ -59,10 +60,29 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict
     const int64_t D = rows_dev ? rows_dev[p] : pd.rows;
     reduce_partials(gram_part, pd.unit_begin * pack, (pd.unit_begin + pd.unit_count) * pack, n * n, red, G);
 
+    // Centred rows sum to zero, so 1/sqrt(N) is an exact null vector of Tc.  The fp32-product Gram
+    // only resolves sigma down to ~1e-4 sigma_0, so deflate that direction explicitly in fp64:
+    // G <- C G C, C = I - 11^T/N.  (LAPACK reports ~1e-7 sigma_0 noise there; we report ~0.)
+    if (center) {
+        if (tid < n) {
+            double s = 0.0;
+            for (int j = 0; j < n; ++j) s += 0.5 * (G[tid * n + j] + G[j * n + tid]);
+            rowoff[tid] = s / n;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int j = 0; j < n; ++j) s += rowoff[j];
+            lam[0] = s / n;
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < n * n; e += EIG_THREADS) {
         const int i = e / n, j = e % n;
         // G is symmetric by construction (same products, same order); average anyway.
-        A[i * LDN + j] = 0.5 * (G[i * n + j] + G[j * n + i]);
+        double a = 0.5 * (G[i * n + j] + G[j * n + i]);
+        if (center) a = a - rowoff[i] - rowoff[j] + lam[0];
+        A[i * LDN + j] = a;
         V[i * LDN + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
@@ -181,16 +201,64 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict
         energy_out[p] = (kk > 0 && r > 0) ? cum[kk - 1] : 0.f;
         rows_out[p] = D;
     }
-    // W[t][i] = sgn_i V[t][order[i]] / sigma_i ; directions below fp32 resolution of the data
-    // (sigma_i <= 1e-6 sigma_0, e.g. the null direction created by centring) are emitted as zero
-    // columns -- LAPACK returns an arbitrary unit vector there ("null directions").
+    // W[t][i] = sgn_i V[t][order[i]] / sigma_i.  Directions with sigma_i <= 1e-6 sigma_0 are below the
+    // fp32 resolution of the data (LAPACK returns an arbitrary unit vector orthogonal to the rest
+    // there).  The first such direction -- the one centring always creates -- gets an explicit
+    // orthonormal completion u = (e_0 - U U[0,:]^T) / norm, i.e. one more W column
+    // w[t] = -(sum_j W[t][j] U[0][j]) / norm plus a spike 1/norm at row 0 (added in pass 2);
+    // any further null directions are zero columns ("null directions").
     const double s0 = sig[0];
     for (int e = tid; e < n * n; e += EIG_THREADS) {
         const int t = e / n, i = e % n;
         double wv = 0.0;
         if (i < r && sig[i] > 1e-6 * s0 && sig[i] > 0.0) wv = sgn[i] * V[t * LDN + order[i]] / sig[i];
-        Wtab[(size_t)p * n * n + e] = (float)wv;
+        A[t * LDN + i] = wv;  // A is free after the sweeps
     }
+    float *aux = Wtab + (size_t)p * (n * n + 4) + n * n;
+    if (tid < n && D > 0) lam[tid] = (double)ptrs[(size_t)p * n + tid][0];  // row 0 of every task
+    __syncthreads();
+    if (tid == 0) {
+        int i0 = -1;
+        if (s0 > 0.0 && D > 0)
+            for (int i = 0; i < r; ++i)
+                if (!(sig[i] > 1e-6 * s0)) {
+                    i0 = i;
+                    break;
+                }
+        float spike = 0.f;
+        if (i0 >= 0) {
+            // centre row 0 exactly as the streaming kernels do (fp32, task order, one divide)
+            float sum = 0.f;
+            for (int t = 0; t < n; ++t) sum += (float)lam[t];
+            const float mean0 = center ? sum / (float)n : 0.f;
+            double norm2 = 1.0;
+            for (int j = 0; j < r; ++j) {
+                double u = 0.0;
+                for (int t = 0; t < n; ++t) u += (double)((float)lam[t] - mean0) * A[t * LDN + j];
+                rowoff[j] = u;  // U[0][j]
+                norm2 -= u * u;
+            }
+            if (norm2 > 0.25) {
+                const double inv = 1.0 / sqrt(norm2);
+                for (int t = 0; t < n; ++t) {
+                    double acc = 0.0;
+                    for (int j = 0; j < r; ++j) acc += A[t * LDN + j] * rowoff[j];
+                    sgn[t] = -inv * acc;
+                }
+                for (int t = 0; t < n; ++t) A[t * LDN + i0] = sgn[t];
+                spike = (float)inv;
+            } else {
+                i0 = -1;
+            }
+        }
+        aux[0] = spike;
+        aux[1] = (float)i0;
+        aux[2] = 0.f;
+        aux[3] = 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += EIG_THREADS)
+        Wtab[(size_t)p * (n * n + 4) + e] = (float)A[(e / n) * LDN + (e % n)];
 }
 
 // ------------------------------------------------------------------------------------ epilogue
@@ -272,11 +340,12 @@ __global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restri
 }
 
 // ------------------------------------------------------------------------------------ launchers
-int svdq_launch_eig(const svdq_plan *pl, const int64_t *rows_dev, const double *gram_part, float *W, uint8_t *small,
+int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W, uint8_t *small,
                     hipStream_t st) {
     const svdq_small_layout &L = pl->small;
-    hipLaunchKernelGGL(k_eig, dim3(pl->n_params), dim3(EIG_THREADS), 0, st, pl->d_params, rows_dev, pl->n_tasks,
-                       pl->pack, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part, W,
+    hipLaunchKernelGGL(k_eig, dim3(pl->n_params), dim3(EIG_THREADS), 0, st, pl->d_params,
+                       reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks,
+                       pl->pack, pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part, W,
                        reinterpret_cast<float *>(small + L.sigma_off), reinterpret_cast<int32_t *>(small + L.k_off),
                        reinterpret_cast<int32_t *>(small + L.r_off), reinterpret_cast<float *>(small + L.energy_off),
                        reinterpret_cast<int64_t *>(small + L.rows_off));

@@ -250,7 +250,9 @@ __global__ __launch_bounds__(64) void k_basis_project(
     const int c = lane & 15, g = lane >> 4;
 
     // W = V Sigma^-1 (columns >= r and null directions are already zero), B-operand registers.
-    const float *Wp = Wtab + (size_t)p * NT * NT;
+    const float *Wp = Wtab + (size_t)p * (NT * NT + 4);
+    const float spike = Wp[NT * NT];
+    const int nullcol = (int)Wp[NT * NT + 1];
     float w[KS][NB];
     float whi[KS];
 #pragma unroll
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(64) void k_basis_project(
                     u = mfma4(a0, w[s][0], u);
                     u = mfma4(a1, whi[s], u);
                 }
+                if (j == 0 && rb == 0 && lane == i && i == nullcol) u[0] += spike;  // row 0 of the completion column
                 f32x4 uh;
                 const int row0 = 32 * j + 16 * (c >> 3) + 4 * g;
 #pragma unroll
@@ -353,6 +356,11 @@ __global__ __launch_bounds__(64) void k_basis_project(
                     const float a = X[(4 * s + g) * XS + 16 * j + c];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) u[nb] = mfma4(a, w[s][nb], u[nb]);
+                }
+                if (j == 0 && rb == 0 && g == 0) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        if (16 * nb + c == nullcol) u[nb][0] += spike;  // row 0 of the completion column
                 }
                 f32x4 uh[NB];
                 const int row0 = 16 * j + 4 * g;

@@ -142,9 +142,9 @@ class CompressPlan:
         nat.check(self.lib.svdq_gram_center(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace),
                                             _stream_ptr()), "svdq_gram_center")
 
-    def eig_rank_select(self, rows_dev=None):
-        nat.check(self.lib.svdq_eig_rank_select(self._h, _ptr(rows_dev), _ptr(self.workspace), _ptr(self.small),
-                                                _stream_ptr()), "svdq_eig_rank_select")
+    def eig_rank_select(self, table, rows_dev=None):
+        nat.check(self.lib.svdq_eig_rank_select(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace),
+                                                _ptr(self.small), _stream_ptr()), "svdq_eig_rank_select")
 
     def basis_project(self, table, rows_dev=None):
         nat.check(self.lib.svdq_basis_project(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace),
