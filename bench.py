@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""
+bench.py -- throughput of the SVD-Hybrid compressor hot path on MI355X.
+
+Metric (BASELINE.json): MParams/s SVD+RTVQ compressed, ViT-L-14 x 8 tasks.
+  Params = N * sum(D_p) task-vector scalars consumed.
+  A "step" = one pass of the whole path (gram -> eig/rank -> basis+projection -> coefficient
+  quantization: 4 launches) over every parameter tensor of the workload, timed from "N task-delta
+  buffers resident in HBM" to "all artifacts (U_high/U_low fp16, mean, sigma, k, c_high fp16, codes,
+  scale, zero_point) resident in HBM".  No disk I/O, no H2D of inputs, no Python dict assembly.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--model ViT-L-14] [--tasks 8]
+                  [--scaling weak|strong] [--no-cpu]
+
+N > 1: launched by torch.distributed.run, one rank per GPU (RCCL).  Parameter tensors are
+independent units: ranks take disjoint tensors, no data-path collective; the packed small artifacts
+(KB..MB) are all-gathered at the end of every step, inside the timed region; the fp16 bases stay on
+their owning GPU.  "weak": every rank processes one full model's worth of
+tensors (per-GPU work fixed).  "strong": one model's tensors are LPT-partitioned over the ranks.
+
+The JSON line also carries
+  roofline      for the dominant kernel (k_basis_project): algorithmic bytes D*(4N + 2N + 4) per row
+                (read every delta once, write U fp16, write mean fp32) / its HIP-event time
+  cpu_baseline  the CPU oracle (reference op sequence on torch-CPU/LAPACK) timed on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="ViT-L-14")
+    ap.add_argument("--tasks", type=int, default=8)
+    ap.add_argument("--energy", type=float, default=0.9)
+    ap.add_argument("--bits", type=int, default=4)
+    ap.add_argument("--stages", type=int, default=2)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--unit-rows", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota and by the
+    16-core share a one-GPU box grants (asking torch for all 256 logical CPUs oversubscribes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("SVDQ_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(names, rows, n_tasks, args):
+    """The oracle (torch-CPU restatement of the reference op sequence) on a bounded sample of the
+    same workload: whole transformer blocks, as many as fit in ~args.cpu_seconds."""
+    from oracle import svd_hybrid_oracle as orc
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    # sample = leading resblocks (12 tensors each) + the global tensors
+    blocks = {}
+    for i, n in enumerate(names):
+        key = n.split(".")[2] if n.startswith("transformer.resblocks.") else "global"
+        blocks.setdefault(key, []).append(i)
+    order = [k for k in blocks if k != "global"]
+    scalars, spent = 0, 0.0
+    sample_desc = []
+    warm = orc.synthetic_deltas(4096, n_tasks, 1)
+    orc.compress_parameter(warm, args.energy, 64, True, True, args.bits, args.stages)
+    for bk in ["global"] + order:
+        for i in blocks[bk]:
+            deltas = orc.synthetic_deltas(rows[i], n_tasks, 1000 + i)
+            t1 = time.perf_counter()
+            orc.compress_parameter(deltas, args.energy, 64, True, True, args.bits, args.stages)
+            spent += time.perf_counter() - t1
+            scalars += rows[i] * n_tasks
+            del deltas
+        sample_desc.append(bk)
+        if spent >= args.cpu_seconds:
+            break
+    return {"value": round(scalars / spent / 1e6, 2), "unit": "MParams/s", "cores": threads, "kind": "port",
+            "sample": f"{args.model} x {n_tasks} tasks: tensors of [{', '.join(sample_desc[:2])}"
+                      f"{' ...' if len(sample_desc) > 2 else ''}] = {len(sample_desc) - 1} resblocks + globals, "
+                      f"{scalars / 1e6:.1f} M scalars in {spent:.1f} s (oracle: torch-CPU stack/mean/gesdd/project + C quantizer)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import svdq_amd
+    from svdq_amd import workloads, shard
+    from svdq_amd.pipeline import CompressPlan
+
+    shapes = workloads.vit_visual_shapes(args.model)
+    names = sorted(shapes)
+    rows_all = [workloads.numel(shapes[n]) for n in names]
+    if world > 1 and args.scaling == "strong":
+        mine = shard.partition_lpt(rows_all, world)[rank]
+    else:
+        mine = list(range(len(names)))
+    rows = [rows_all[i] for i in mine]
+    N = args.tasks
+
+    bufs, views = workloads.synth_task_buffers(rows, N, seed=1234 + rank, device=dev)
+    plan = CompressPlan(rows, N, energy_threshold=args.energy, max_rank=64, center=True, fp16=True,
+                        low_bits=args.bits, rtvq_stages=args.stages, device=dev, unit_rows=args.unit_rows)
+    table = plan.pointer_table(views)
+    torch.cuda.synchronize()
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+
+    def step(events=None):
+        if events is None:
+            plan.run(table)
+        else:
+            events[0].record(); plan.gram_center(table)
+            events[1].record(); plan.eig_rank_select(table)
+            events[2].record(); plan.basis_project(table)
+            events[3].record(); plan.coeff_quantize()
+            events[4].record()
+        if world > 1:
+            shard.gather_small(plan.small)
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(ev[s])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tot = torch.tensor([float(sum(rows)) * N], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_scalars = float(tot.item())
+    else:
+        total_scalars = float(sum(rows)) * N
+
+    # per-kernel HIP-event times (this rank), averaged over the timed steps
+    kms = [0.0] * 4
+    for s in range(args.steps):
+        for i in range(4):
+            kms[i] += ev[s][i].elapsed_time(ev[s][i + 1])
+    kms = [x / args.steps for x in kms]
+
+    sm = plan.fetch_small()
+    k_mean = float(sm.k.mean())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_scalars / (elapsed / args.steps) / 1e6
+        sumD = float(sum(rows))
+        bp_bytes = sumD * (4 * N + 2 * N + 4)            # k_basis_project: read deltas once, write U fp16 + mean
+        gram_bytes = sumD * 4 * N                         # k_gram: read deltas once
+        bp_gbs = bp_bytes / (kms[2] * 1e-3) / 1e9
+        path_bytes = sumD * (6 * N + 4)                   # whole path, deltas counted ONCE
+        out = {
+            "metric": "MParams/s SVD+RTVQ compressed (Params = N_tasks * sum D_p task-vector scalars)",
+            "value": round(value, 1), "unit": "MParams/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.model} visual encoder x {N} tasks, {len(rows)} tensors/GPU, "
+                                   f"sum D = {int(sumD)}/GPU, energy {args.energy}, center, fp16 bases, "
+                                   f"{args.bits}-bit x {args.stages}-stage RTVQ",
+                       "tensors_per_gpu": len(rows), "tasks": N, "mean_rank_k": round(k_mean, 2),
+                       "units": int(plan.sizes.n_units),
+                       "sharding": "none" if world == 1 else (
+                           "one model per rank" if args.scaling == "weak" else "LPT over parameter tensors")},
+            "roofline": {"bound": "hbm", "kernel": "k_basis_project", "achieved": round(bp_gbs, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bp_gbs / HBM_PEAK_GBS, 4),
+                         "traffic": None, "algorithmic_bytes": int(bp_bytes), "avg_ms": round(kms[2], 4)},
+            "kernels_ms": {"k_gram": round(kms[0], 4), "k_eig": round(kms[1], 4),
+                           "k_basis_project": round(kms[2], 4), "k_coeff": round(kms[3], 4)},
+            "roofline_gram": {"bound": "hbm", "kernel": "k_gram",
+                              "achieved": round(gram_bytes / (kms[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(gram_bytes / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "algorithmic_bytes": int(gram_bytes)},
+            "path_roofline_frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        }
+        if not args.no_cpu and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline([names[i] for i in mine], rows, N, args)
+            except Exception as e:  # the checker must never sink the measurement
+                out["cpu_baseline"] = {"value": None, "error": str(e)[:200]}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
