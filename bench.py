@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--stages", type=int, default=2)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--unit-rows", type=int, default=0)
+    ap.add_argument("--pipeline-mb", type=float, default=0.0,
+                    help="experimental: group parameters into >= this many MB of input and pipeline "
+                         "gram(g+1) | eig(g) on a side stream | basis_project(g) so a group's deltas are still "
+                         "in the Infinity Cache for its second pass (0 = four whole-model launches)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -140,8 +144,38 @@ def main():
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
 
+    # optional pipelined schedule over groups of consecutive parameters
+    groups = []
+    if args.pipeline_mb > 0:
+        p0, acc = 0, 0.0
+        for i, d in enumerate(rows):
+            acc += d * N * 4 / 1e6
+            if acc >= args.pipeline_mb or i == len(rows) - 1:
+                groups.append((p0, i + 1 - p0))
+                p0, acc = i + 1, 0.0
+    side = torch.cuda.Stream(device=dev) if groups else None
+    gev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in groups]
+
+    def step_pipelined():
+        main = torch.cuda.current_stream()
+        G = len(groups)
+        plan.gram_range(table, *groups[0], main)
+        gev[0][0].record(main)
+        for g in range(G):
+            side.wait_event(gev[g][0])
+            plan.eig_range(table, *groups[g], side)
+            gev[g][1].record(side)
+            if g + 1 < G:
+                plan.gram_range(table, *groups[g + 1], main)
+                gev[g + 1][0].record(main)
+            main.wait_event(gev[g][1])
+            plan.bp_range(table, *groups[g], main)
+        plan.coeff_range(0, len(rows), main)
+
     def step(events=None):
-        if events is None:
+        if groups:
+            step_pipelined()
+        elif events is None:
             plan.run(table)
         else:
             events[0].record(); plan.gram_center(table)
@@ -177,10 +211,13 @@ def main():
 
     # per-kernel HIP-event times (this rank), averaged over the timed steps
     kms = [0.0] * 4
-    for s in range(args.steps):
-        for i in range(4):
-            kms[i] += ev[s][i].elapsed_time(ev[s][i + 1])
-    kms = [x / args.steps for x in kms]
+    if not groups:
+        for s in range(args.steps):
+            for i in range(4):
+                kms[i] += ev[s][i].elapsed_time(ev[s][i + 1])
+        kms = [x / args.steps for x in kms]
+    else:
+        kms = [float("nan")] * 4
 
     sm = plan.fetch_small()
     k_mean = float(sm.k.mean())
@@ -191,7 +228,7 @@ def main():
         sumD = float(sum(rows))
         bp_bytes = sumD * (4 * N + 2 * N + 4)            # k_basis_project: read deltas once, write U fp16 + mean
         gram_bytes = sumD * 4 * N                         # k_gram: read deltas once
-        bp_gbs = bp_bytes / (kms[2] * 1e-3) / 1e9
+        bp_gbs = bp_bytes / (kms[2] * 1e-3) / 1e9 if kms[2] == kms[2] else float("nan")
         path_bytes = sumD * (6 * N + 4)                   # whole path, deltas counted ONCE
         out = {
             "metric": "MParams/s SVD+RTVQ compressed (Params = N_tasks * sum D_p task-vector scalars)",
@@ -203,7 +240,7 @@ def main():
                                    f"sum D = {int(sumD)}/GPU, energy {args.energy}, center, fp16 bases, "
                                    f"{args.bits}-bit x {args.stages}-stage RTVQ",
                        "tensors_per_gpu": len(rows), "tasks": N, "mean_rank_k": round(k_mean, 2),
-                       "units": int(plan.sizes.n_units),
+                       "units": int(plan.sizes.n_units), "pipeline_groups": len(groups),
                        "sharding": "none" if world == 1 else (
                            "one model per rank" if args.scaling == "weak" else "LPT over parameter tensors")},
             "roofline": {"bound": "hbm", "kernel": "k_basis_project", "achieved": round(bp_gbs, 1),

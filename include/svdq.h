@@ -135,6 +135,21 @@ int svdq_basis_project(const svdq_plan *plan, const void *delta_ptrs_dev, const 
  *      c_low -> RTVQQuantizer.quantize rtvq.py:39-82, for every (parameter, task)). */
 int svdq_coeff_quantize(const svdq_plan *plan, void *workspace_dev, void *small_dev, void *stream);
 
+/* ---- the same four stages restricted to parameters [param0, param0 + nparams) of the plan.
+ *      They let a caller pipeline groups of parameters (gram of group g+1 while the eigen-solve
+ *      of group g runs on a second stream), which keeps a group's deltas resident in the 256 MiB
+ *      Infinity Cache between its two streaming passes ("cache-resident pipeline"). */
+int svdq_gram_center_range(const svdq_plan *plan, const void *delta_ptrs_dev, const int64_t *rows_dev,
+                           void *workspace_dev, int32_t param0, int32_t nparams, void *stream);
+int svdq_eig_rank_select_range(const svdq_plan *plan, const void *delta_ptrs_dev, const int64_t *rows_dev,
+                               void *workspace_dev, void *small_dev, int32_t param0, int32_t nparams,
+                               void *stream);
+int svdq_basis_project_range(const svdq_plan *plan, const void *delta_ptrs_dev, const int64_t *rows_dev,
+                             void *workspace_dev, const void *small_dev, void *basis_dev, float *mean_dev,
+                             int32_t param0, int32_t nparams, void *stream);
+int svdq_coeff_quantize_range(const svdq_plan *plan, void *workspace_dev, void *small_dev, int32_t param0,
+                              int32_t nparams, void *stream);
+
 /* ---- all four stages back to back on one stream (cli.py Step 4 + Step 5 for the batch) ---- */
 int svdq_compress(const svdq_plan *plan, const void *delta_ptrs_dev, const int64_t *rows_dev,
                   void *workspace_dev, void *small_dev, void *basis_dev, float *mean_dev, void *stream);

@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_ui
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
-LIB_PATH = os.path.join(_PKG_DIR, "libsvdq_hip.so")
+LIB_PATH = os.environ.get("SVDQ_LIB_PATH") or os.path.join(_PKG_DIR, "libsvdq_hip.so")
 
 SVDQ_OK, SVDQ_EINVAL, SVDQ_EHIP, SVDQ_EUNSUPPORTED = 0, -1, -2, -3
 MASK_STRATEGIES = {"union": 0, "intersection": 1, "majority": 2}
@@ -51,6 +51,12 @@ SIGNATURES = {
     "svdq_eig_rank_select": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_basis_project": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_coeff_quantize": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_gram_center_range": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "svdq_eig_rank_select_range": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                             c_void_p]),
+    "svdq_basis_project_range": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int32, c_int32, c_void_p]),
+    "svdq_coeff_quantize_range": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "svdq_compress": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_rtvq_work_bytes": (c_int64, [c_int64]),
     "svdq_rtvq_quantize": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p,

@@ -30,9 +30,12 @@ extern "C" int svdq_abi_version(void) { return SVDQ_ABI_VERSION; }
 extern "C" const char *svdq_last_error(void) { return g_err; }
 
 static int32_t auto_unit_rows(int64_t D) {
-    // about 256 units for the large matrices (load balance over 256 CUs x ~12 waves),
-    // never fewer than 4 blocks per unit so the per-unit fp64 partial stays < 1 % of the traffic
-    int64_t ur = svdq_align_up((D + 255) / 256, SVDQ_BLK_ROWS);
+    // Measured on MI355X, ViT-L-14 x 8 (bench.py --unit-rows sweep): 4096..8192-row units are best --
+    // smaller units multiply the fp64 partial slots the two small kernels must reduce, larger ones
+    // leave a long tail on the 256 CUs x ~12 resident waves.  Small tensors get >= 4 units when they
+    // have the rows for it, never less than 4 blocks per unit.
+    int64_t ur = 8192;
+    if (D < 4 * ur) ur = svdq_align_up((D + 3) / 4, SVDQ_BLK_ROWS);
     if (ur < 4 * SVDQ_BLK_ROWS) ur = 4 * SVDQ_BLK_ROWS;
     return (int32_t)ur;
 }
@@ -130,6 +133,8 @@ extern "C" int svdq_plan_create(svdq_plan **out, int32_t n_tasks, int32_t n_para
     off += svdq_align_up((int64_t)pl->n_slots * nn * 8, 256);
     pl->ws_w_off = off;
     off += svdq_align_up((int64_t)n_params * (nn + 4) * 4, 256);  // W [N][N] + {spike, null column, -, -}
+    pl->ws_c0_off = off;
+    off += svdq_align_up((int64_t)n_params * nn * 8, 256);        // closed-form coefficients of the unrounded basis
     pl->sizes.workspace_bytes = off;
     pl->sizes.basis_bytes = basis_bytes;
     pl->sizes.mean_floats = mean_floats;
@@ -200,29 +205,50 @@ extern "C" int svdq_plan_basis_layout(const svdq_plan *pl, int64_t *slab_off, in
 
 static inline uint8_t *ws(void *base, int64_t off) { return reinterpret_cast<uint8_t *>(base) + off; }
 
-extern "C" int svdq_gram_center(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
-                                void *stream) {
+static int check_range(const svdq_plan *pl, int32_t param0, int32_t nparams) {
+    if (param0 < 0 || nparams < 1 || param0 + nparams > pl->n_params) {
+        svdq_set_error("parameter range [%d, %d) outside [0, %d)", param0, param0 + nparams, pl->n_params);
+        return SVDQ_EINVAL;
+    }
+    return SVDQ_OK;
+}
+
+static void unit_range(const svdq_plan *pl, int32_t param0, int32_t nparams, int *u0, int *nu) {
+    const SvdqParam &a = pl->h_params[param0], &b = pl->h_params[param0 + nparams - 1];
+    *u0 = a.unit_begin;
+    *nu = b.unit_begin + b.unit_count - a.unit_begin;
+}
+
+extern "C" int svdq_gram_center_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                                      int32_t param0, int32_t nparams, void *stream) {
     if (!pl || !ptrs || !workspace) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
     }
-    return svdq_launch_gram(pl, ptrs, rows_dev, reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off)),
+    if (int rc = check_range(pl, param0, nparams)) return rc;
+    int u0, nu;
+    unit_range(pl, param0, nparams, &u0, &nu);
+    return svdq_launch_gram(pl, ptrs, rows_dev, reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off)), u0, nu,
                             (hipStream_t)stream);
 }
 
-extern "C" int svdq_eig_rank_select(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
-                                    void *small, void *stream) {
+extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
+                                          void *workspace, void *small, int32_t param0, int32_t nparams,
+                                          void *stream) {
     if (!pl || !ptrs || !workspace || !small) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
     }
+    if (int rc = check_range(pl, param0, nparams)) return rc;
     return svdq_launch_eig(pl, ptrs, rows_dev, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram_off)),
-                           reinterpret_cast<float *>(ws(workspace, pl->ws_w_off)), reinterpret_cast<uint8_t *>(small),
-                           (hipStream_t)stream);
+                           reinterpret_cast<float *>(ws(workspace, pl->ws_w_off)),
+                           reinterpret_cast<double *>(ws(workspace, pl->ws_c0_off)), reinterpret_cast<uint8_t *>(small),
+                           param0, nparams, (hipStream_t)stream);
 }
 
-extern "C" int svdq_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
-                                  const void *small, void *basis, float *mean, void *stream) {
+extern "C" int svdq_basis_project_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
+                                        void *workspace, const void *small, void *basis, float *mean, int32_t param0,
+                                        int32_t nparams, void *stream) {
     if (!pl || !ptrs || !workspace || !small || !basis) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
@@ -231,21 +257,51 @@ extern "C" int svdq_basis_project(const svdq_plan *pl, const void *ptrs, const i
         svdq_set_error("basis buffer must be 256-byte aligned");
         return SVDQ_EINVAL;
     }
+    if (int rc = check_range(pl, param0, nparams)) return rc;
+    int u0, nu;
+    unit_range(pl, param0, nparams, &u0, &nu);
     const uint8_t *sm = reinterpret_cast<const uint8_t *>(small);
     return svdq_launch_basis_project(pl, ptrs, rows_dev, reinterpret_cast<const float *>(ws(workspace, pl->ws_w_off)),
                                      reinterpret_cast<const int32_t *>(sm + pl->small.k_off),
                                      reinterpret_cast<const int32_t *>(sm + pl->small.r_off),
                                      reinterpret_cast<uint8_t *>(basis), mean,
-                                     reinterpret_cast<double *>(ws(workspace, pl->ws_cpart_off)), (hipStream_t)stream);
+                                     reinterpret_cast<double *>(ws(workspace, pl->ws_cpart_off)), u0, nu,
+                                     pl->cfg.reserved & 1, (hipStream_t)stream);
 }
 
-extern "C" int svdq_coeff_quantize(const svdq_plan *pl, void *workspace, void *small, void *stream) {
+extern "C" int svdq_coeff_quantize_range(const svdq_plan *pl, void *workspace, void *small, int32_t param0,
+                                         int32_t nparams, void *stream) {
     if (!pl || !workspace || !small) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
     }
+    if (int rc = check_range(pl, param0, nparams)) return rc;
     return svdq_launch_coeff(pl, reinterpret_cast<const double *>(ws(workspace, pl->ws_cpart_off)),
-                             reinterpret_cast<uint8_t *>(small), (hipStream_t)stream);
+                             reinterpret_cast<const double *>(ws(workspace, pl->ws_c0_off)),
+                             reinterpret_cast<uint8_t *>(small), param0, nparams, (hipStream_t)stream);
+}
+
+extern "C" int svdq_gram_center(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                                void *stream) {
+    if (!pl) return SVDQ_EINVAL;
+    return svdq_gram_center_range(pl, ptrs, rows_dev, workspace, 0, pl->n_params, stream);
+}
+
+extern "C" int svdq_eig_rank_select(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                                    void *small, void *stream) {
+    if (!pl) return SVDQ_EINVAL;
+    return svdq_eig_rank_select_range(pl, ptrs, rows_dev, workspace, small, 0, pl->n_params, stream);
+}
+
+extern "C" int svdq_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                                  const void *small, void *basis, float *mean, void *stream) {
+    if (!pl) return SVDQ_EINVAL;
+    return svdq_basis_project_range(pl, ptrs, rows_dev, workspace, small, basis, mean, 0, pl->n_params, stream);
+}
+
+extern "C" int svdq_coeff_quantize(const svdq_plan *pl, void *workspace, void *small, void *stream) {
+    if (!pl) return SVDQ_EINVAL;
+    return svdq_coeff_quantize_range(pl, workspace, small, 0, pl->n_params, stream);
 }
 
 extern "C" int svdq_compress(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,

@@ -15,7 +15,9 @@
 #include "../../include/svdq.h"
 
 #define SVDQ_BLK_ROWS 256
-#define SVDQ_XS 260  // LDS row stride (floats) of one task's 256-row strip: 256 + 4 pad, keeps 16-B alignment
+#ifndef SVDQ_XS
+#define SVDQ_XS 260  // LDS row stride (floats) of one task's 256-row strip: 256 + pad, multiple of 4 (16-B alignment)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -39,7 +41,7 @@ struct svdq_plan {
     svdq_sizes sizes;
     svdq_small_layout small;
     // workspace offsets (bytes)
-    int64_t ws_gram_off, ws_cpart_off, ws_w_off;
+    int64_t ws_gram_off, ws_cpart_off, ws_w_off, ws_c0_off;
     // host copies
     SvdqParam *h_params;
     SvdqUnit *h_units;
@@ -57,10 +59,11 @@ void svdq_set_error(const char *fmt, ...);
 
 // launchers (defined in the .hip files)
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                     hipStream_t st);
+                     int unit0, int nunits, hipStream_t st);
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
-                              double *cpart, hipStream_t st);
+                              double *cpart, int unit0, int nunits, int reverse, hipStream_t st);
 int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W,
-                    uint8_t *small, hipStream_t st);
-int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, uint8_t *small, hipStream_t st);
+                    double *c0, uint8_t *small, int param0, int nparams, hipStream_t st);
+int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, const double *c0, uint8_t *small, int param0,
+                      int nparams, hipStream_t st);

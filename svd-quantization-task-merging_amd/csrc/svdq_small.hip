@@ -20,16 +20,16 @@ __device__ void reduce_partials(const double *__restrict__ part, int s0, int s1,
                                 double *out /*[nn]*/) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     for (int e = l; e < nn; e += 64) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.0;
         int s = s0 + w;
-        for (; s + 12 < s1; s += 16) {
-            a0 += part[(size_t)s * nn + e];
-            a1 += part[(size_t)(s + 4) * nn + e];
-            a2 += part[(size_t)(s + 8) * nn + e];
-            a3 += part[(size_t)(s + 12) * nn + e];
+        for (; s + 28 < s1; s += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += part[(size_t)(s + 4 * u) * nn + e];
         }
-        for (; s < s1; s += 4) a0 += part[(size_t)s * nn + e];
-        red[w * 1024 + e] = (a0 + a1) + (a2 + a3);
+        for (; s < s1; s += 4) a[0] += part[(size_t)s * nn + e];
+        red[w * 1024 + e] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     __syncthreads();
     for (int e = tid; e < nn; e += EIG_THREADS)
@@ -41,11 +41,16 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict
                                                      const float *const *__restrict__ ptrs,
                                                      const int64_t *__restrict__ rows_dev, int NT, int pack,
                                                      int center, float thr, int max_rank, const double *__restrict__ gram_part,
-                                                     float *__restrict__ Wtab, float *__restrict__ sigma_out,
+                                                     float *__restrict__ Wtab, double *__restrict__ c0_out, int param0,
+                                                     float *__restrict__ sigma_out,
                                                      int32_t *__restrict__ k_out, int32_t *__restrict__ r_out,
                                                      float *__restrict__ energy_out, int64_t *__restrict__ rows_out) {
     __shared__ double red[4 * 1024];
     __shared__ double G[1024];
+    __shared__ double Gd[1024];
+    __shared__ double xc0[32];
+    __shared__ int s_i0;
+    __shared__ double s_spike;
     __shared__ double A[32 * LDN];
     __shared__ double V[32 * LDN];
     __shared__ double lam[32];
@@ -54,8 +59,10 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict
     __shared__ double sgn[32];
     __shared__ double sig[32];
     __shared__ int done;
+    __shared__ int pr_p[16], pr_q[16];
+    __shared__ double pr_c[16], pr_s[16];
 
-    const int p = blockIdx.x, tid = threadIdx.x, n = NT;
+    const int p = param0 + blockIdx.x, tid = threadIdx.x, n = NT;
     const SvdqParam pd = params[p];
     const int64_t D = rows_dev ? rows_dev[p] : pd.rows;
     reduce_partials(gram_part, pd.unit_begin * pack, (pd.unit_begin + pd.unit_count) * pack, n * n, red, G);
@@ -82,12 +89,18 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict
         // G is symmetric by construction (same products, same order); average anyway.
         double a = 0.5 * (G[i * n + j] + G[j * n + i]);
         if (center) a = a - rowoff[i] - rowoff[j] + lam[0];
+        Gd[i * n + j] = a;  // deflated Gram, kept for the completion column's coefficients
         A[i * LDN + j] = a;
         V[i * LDN + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
 
-    for (int sweep = 0; sweep < 60; ++sweep) {
+    // Parallel-order cyclic Jacobi: a round-robin tournament pairs all indices into M = ceil(n/2)
+    // disjoint (p,q) per round (n_even - 1 rounds per sweep); the M rotations of a round commute, so
+    // they are applied together: A <- A J (columns), then A <- J^T A (rows), V <- V J.
+    // 3 barriers per ROUND instead of 2 per rotation: ~5x less latency at n = 8, ~10x at n = 32.
+    const int M = (n + 1) >> 1, ne = 2 * M;
+    for (int sweep = 0; sweep < 40; ++sweep) {
         if (tid < n) {
             double off = 0.0;
             for (int j = 0; j < n; ++j)
@@ -101,47 +114,62 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict
                 off += rowoff[j];
                 dg += A[j * LDN + j] * A[j * LDN + j];
             }
-            done = (off <= 1e-32 * dg) || (dg == 0.0);
+            done = (off <= 1e-30 * dg) || (dg == 0.0);
         }
         __syncthreads();
-        if (done) break;
-        for (int pp = 0; pp < n - 1; ++pp) {
-            for (int q = pp + 1; q < n; ++q) {
-                const double app = A[pp * LDN + pp], aqq = A[q * LDN + q], apq = A[pp * LDN + q];
-                double ajp = 0.0, ajq = 0.0, vjp = 0.0, vjq = 0.0;
-                if (tid < n) {
-                    ajp = A[tid * LDN + pp];
-                    ajq = A[tid * LDN + q];
-                    vjp = V[tid * LDN + pp];
-                    vjq = V[tid * LDN + q];
+        if (done || n < 2) break;
+        for (int rd = 0; rd < ne - 1; ++rd) {
+            if (tid < M) {
+                int a, b;
+                if (tid == 0) {
+                    a = ne - 1;
+                    b = rd;
+                } else {
+                    a = (rd + tid) % (ne - 1);
+                    b = (rd - tid + (ne - 1)) % (ne - 1);
                 }
-                __syncthreads();
-                if (apq != 0.0) {
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    const double cs = 1.0 / sqrt(1.0 + t * t);
-                    const double sn = t * cs;
-                    if (tid < n) {
-                        if (tid != pp && tid != q) {
-                            const double np_ = cs * ajp - sn * ajq;
-                            const double nq_ = sn * ajp + cs * ajq;
-                            A[tid * LDN + pp] = np_;
-                            A[pp * LDN + tid] = np_;
-                            A[tid * LDN + q] = nq_;
-                            A[q * LDN + tid] = nq_;
-                        }
-                        V[tid * LDN + pp] = cs * vjp - sn * vjq;
-                        V[tid * LDN + q] = sn * vjp + cs * vjq;
-                        if (tid == pp) {
-                            A[pp * LDN + pp] = app - t * apq;
-                            A[q * LDN + q] = aqq + t * apq;
-                            A[pp * LDN + q] = 0.0;
-                            A[q * LDN + pp] = 0.0;
-                        }
+                const int pp = a < b ? a : b, q = a < b ? b : a;
+                double cs = 1.0, sn = 0.0;
+                if (q < n) {
+                    const double app = A[pp * LDN + pp], aqq = A[q * LDN + q], apq = A[pp * LDN + q];
+                    if (apq != 0.0) {
+                        const double tau = (aqq - app) / (2.0 * apq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        cs = 1.0 / sqrt(1.0 + t * t);
+                        sn = t * cs;
                     }
                 }
-                __syncthreads();
+                pr_p[tid] = pp;
+                pr_q[tid] = q;
+                pr_c[tid] = cs;
+                pr_s[tid] = sn;
             }
+            __syncthreads();
+            for (int e = tid; e < n * M; e += EIG_THREADS) {  // columns of A and V
+                const int i = e / M, m = e % M;
+                const int pp = pr_p[m], q = pr_q[m];
+                if (q < n) {
+                    const double cs = pr_c[m], sn = pr_s[m];
+                    const double x = A[i * LDN + pp], y = A[i * LDN + q];
+                    A[i * LDN + pp] = cs * x - sn * y;
+                    A[i * LDN + q] = sn * x + cs * y;
+                    const double vx = V[i * LDN + pp], vy = V[i * LDN + q];
+                    V[i * LDN + pp] = cs * vx - sn * vy;
+                    V[i * LDN + q] = sn * vx + cs * vy;
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < n * M; e += EIG_THREADS) {  // rows of A
+                const int j = e / M, m = e % M;
+                const int pp = pr_p[m], q = pr_q[m];
+                if (q < n) {
+                    const double cs = pr_c[m], sn = pr_s[m];
+                    const double x = A[pp * LDN + j], y = A[q * LDN + j];
+                    A[pp * LDN + j] = (j == q) ? 0.0 : cs * x - sn * y;
+                    A[q * LDN + j] = (j == pp) ? 0.0 : sn * x + cs * y;
+                }
+            }
+            __syncthreads();
         }
     }
 
@@ -232,9 +260,10 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict
             for (int t = 0; t < n; ++t) sum += (float)lam[t];
             const float mean0 = center ? sum / (float)n : 0.f;
             double norm2 = 1.0;
+            for (int t = 0; t < n; ++t) xc0[t] = (double)((float)lam[t] - mean0);
             for (int j = 0; j < r; ++j) {
                 double u = 0.0;
-                for (int t = 0; t < n; ++t) u += (double)((float)lam[t] - mean0) * A[t * LDN + j];
+                for (int t = 0; t < n; ++t) u += xc0[t] * A[t * LDN + j];
                 rowoff[j] = u;  // U[0][j]
                 norm2 -= u * u;
             }
@@ -243,9 +272,9 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict
                 for (int t = 0; t < n; ++t) {
                     double acc = 0.0;
                     for (int j = 0; j < r; ++j) acc += A[t * LDN + j] * rowoff[j];
-                    sgn[t] = -inv * acc;
+                    lam[t] = -inv * acc;  // lam (row 0 of the tasks) is already folded into xc0
                 }
-                for (int t = 0; t < n; ++t) A[t * LDN + i0] = sgn[t];
+                for (int t = 0; t < n; ++t) A[t * LDN + i0] = lam[t];
                 spike = (float)inv;
             } else {
                 i0 = -1;
@@ -255,10 +284,29 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict
         aux[1] = (float)i0;
         aux[2] = 0.f;
         aux[3] = 0.f;
+        s_i0 = i0;
+        s_spike = (double)spike;
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += EIG_THREADS)
-        Wtab[(size_t)p * (n * n + 4) + e] = (float)A[(e / n) * LDN + (e % n)];
+    // W (fp32) and the closed-form coefficients c0[t][i] = u_i^T xc_t of the UNROUNDED basis:
+    //   real direction:      sigma_i * v_i[t]           (U^T Tc = Sigma V^T)
+    //   completion column:   w^T Gd[:,t] + spike * xc_t[row 0]
+    //   zero column:         0
+    // pass 2 adds the fp16-rounding correction E^T Tc on top (k_coeff sums both).
+    for (int e = tid; e < n * n; e += EIG_THREADS) {
+        const int t = e / n, i = e % n;
+        Wtab[(size_t)p * (n * n + 4) + e] = (float)A[t * LDN + i];
+        double cv = 0.0;
+        if (i < r) {
+            if (i == s_i0) {
+                for (int t2 = 0; t2 < n; ++t2) cv += A[t2 * LDN + i] * Gd[t2 * n + t];
+                cv += s_spike * xc0[t];
+            } else if (sig[i] > 1e-6 * s0 && sig[i] > 0.0) {
+                cv = sig[i] * sgn[i] * V[t * LDN + order[i]];
+            }
+        }
+        c0_out[(size_t)p * n * n + e] = cv;
+    }
 }
 
 // ------------------------------------------------------------------------------------ epilogue
@@ -267,16 +315,17 @@ __device__ __forceinline__ float f_max_nan(float a, float b) { return (a != a) ?
 
 __global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restrict__ params, int NT, int pack,
                                                        int bits, int stages, const double *__restrict__ cpart,
+                                                       const double *__restrict__ c0_in,
                                                        const int32_t *__restrict__ k_in,
                                                        const int32_t *__restrict__ r_in,
                                                        float *__restrict__ coef_out, uint16_t *__restrict__ chigh_out,
                                                        uint8_t *__restrict__ codes_out, float *__restrict__ scale_out,
-                                                       float *__restrict__ zp_out, float *__restrict__ rnorm_out) {
+                                                       float *__restrict__ zp_out, float *__restrict__ rnorm_out, int param0) {
     __shared__ double red[4 * 1024];
     __shared__ double C[1024];
     __shared__ float res[32 * LDN];
 
-    const int p = blockIdx.x, tid = threadIdx.x, n = NT;
+    const int p = param0 + blockIdx.x, tid = threadIdx.x, n = NT;
     const SvdqParam pd = params[p];
     reduce_partials(cpart, pd.unit_begin * pack, (pd.unit_begin + pd.unit_count) * pack, n * n, red, C);
 
@@ -285,7 +334,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restri
     // c[t][i] fp32, c_high fp16 (round-to-nearest-even), zero padding past the valid prefix
     for (int e = tid; e < n * n; e += EIG_THREADS) {
         const int t = e / n, i = e % n;
-        const float cv = (float)C[e];
+        const float cv = (float)(c0_in[(size_t)p * n * n + e] + C[e]);
         coef_out[(size_t)p * n * n + e] = cv;
         chigh_out[(size_t)p * n * n + e] = (i < k) ? __half_as_ushort(__float2half_rn(cv)) : (uint16_t)0;
         if (i >= k && i < r) res[t * LDN + (i - k)] = cv;
@@ -340,25 +389,27 @@ __global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restri
 }
 
 // ------------------------------------------------------------------------------------ launchers
-int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W, uint8_t *small,
-                    hipStream_t st) {
+int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W,
+                    double *c0, uint8_t *small,
+                    int param0, int nparams, hipStream_t st) {
     const svdq_small_layout &L = pl->small;
-    hipLaunchKernelGGL(k_eig, dim3(pl->n_params), dim3(EIG_THREADS), 0, st, pl->d_params,
+    hipLaunchKernelGGL(k_eig, dim3(nparams), dim3(EIG_THREADS), 0, st, pl->d_params,
                        reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks,
-                       pl->pack, pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part, W,
+                       pl->pack, pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part, W, c0, param0,
                        reinterpret_cast<float *>(small + L.sigma_off), reinterpret_cast<int32_t *>(small + L.k_off),
                        reinterpret_cast<int32_t *>(small + L.r_off), reinterpret_cast<float *>(small + L.energy_off),
                        reinterpret_cast<int64_t *>(small + L.rows_off));
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
-int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, uint8_t *small, hipStream_t st) {
+int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, const double *c0, uint8_t *small, int param0,
+                      int nparams, hipStream_t st) {
     const svdq_small_layout &L = pl->small;
-    hipLaunchKernelGGL(k_coeff, dim3(pl->n_params), dim3(EIG_THREADS), 0, st, pl->d_params, pl->n_tasks, pl->pack,
-                       pl->cfg.low_bits, pl->cfg.rtvq_stages, cpart, reinterpret_cast<const int32_t *>(small + L.k_off),
+    hipLaunchKernelGGL(k_coeff, dim3(nparams), dim3(EIG_THREADS), 0, st, pl->d_params, pl->n_tasks, pl->pack,
+                       pl->cfg.low_bits, pl->cfg.rtvq_stages, cpart, c0, reinterpret_cast<const int32_t *>(small + L.k_off),
                        reinterpret_cast<const int32_t *>(small + L.r_off), reinterpret_cast<float *>(small + L.coef_off),
                        reinterpret_cast<uint16_t *>(small + L.chigh_off), small + L.codes_off,
                        reinterpret_cast<float *>(small + L.scale_off), reinterpret_cast<float *>(small + L.zp_off),
-                       reinterpret_cast<float *>(small + L.rnorm_off));
+                       reinterpret_cast<float *>(small + L.rnorm_off), param0);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }

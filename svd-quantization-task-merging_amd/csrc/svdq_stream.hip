@@ -29,6 +29,17 @@
 #include <hip/hip_fp16.h>
 
 #define XS SVDQ_XS
+#ifndef SVDQ_UNROLL_BP
+#define SVDQ_UNROLL_BP 8
+#endif
+#ifndef SVDQ_UNROLL_GRAM
+#define SVDQ_UNROLL_GRAM 8
+#endif
+#ifndef SVDQ_PREFETCH2
+#define SVDQ_PREFETCH2 0  // 1: two register sets, loads two blocks ahead (measured: no gain, fewer waves)
+#endif
+#define PRAGMA_(x) _Pragma(#x)
+#define UNROLL_N(n) PRAGMA_(unroll n)
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -39,16 +50,22 @@ __device__ __forceinline__ f32x4 zero4() {
     return z;
 }
 
+// Task-delta pointers come out of a device table, so the compiler only knows them as generic
+// ("flat") pointers; flat loads count on BOTH vmcnt and lgkmcnt, which would make every LDS wait
+// also drain the next block's prefetch.  Cast them to the global address space explicitly.
+typedef const __attribute__((address_space(1))) float gfloat;
+typedef const __attribute__((address_space(1))) f32x4 gf32x4;
+
 // Issue the 16-B loads of one 256-row block: lane l takes rows rb+4l..rb+4l+3 of every task.
 // Full blocks take the unconditional path (no per-load branch, all loads in flight together);
 // only the last block of a parameter takes the guarded one.
 template <int NTP>
-__device__ __forceinline__ void load_block(f32x4 (&v)[NTP], const float *(&bp)[NTP], int64_t rb,
+__device__ __forceinline__ void load_block(f32x4 (&v)[NTP], gfloat *(&bp)[NTP], int64_t rb,
                                            int64_t D, int lane) {
     const int64_t r = rb + 4 * lane;
     if (rb + SVDQ_BLK_ROWS <= D) {
 #pragma unroll
-        for (int t = 0; t < NTP; ++t) v[t] = *reinterpret_cast<const f32x4 *>(bp[t] + r);
+        for (int t = 0; t < NTP; ++t) v[t] = *reinterpret_cast<gf32x4 *>(bp[t] + r);
     } else {
 #pragma unroll
         for (int t = 0; t < NTP; ++t) {
@@ -94,23 +111,24 @@ __global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ param
                                              const SvdqUnit *__restrict__ units,
                                              const float *const *__restrict__ ptrs,
                                              const int64_t *__restrict__ rows_dev, int NT, int center,
-                                             double *__restrict__ gram_part) {
+                                             double *__restrict__ gram_part, int unit0) {
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
     constexpr int NACC = (NB == 1) ? 1 : 3;  // AA | AA, AB, BB
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
 
     const int lane = threadIdx.x;
-    const SvdqUnit ud = units[blockIdx.x];
+    const int uidx = unit0 + (int)blockIdx.x;
+    const SvdqUnit ud = units[uidx];
     const int p = ud.param;
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
     const int64_t r_begin = ud.row0;
     int64_t r_end = r_begin + ud.nrows;
     if (r_end > D) r_end = D;
 
-    const float *bp[NTP];
+    gfloat *bp[NTP];
 #pragma unroll
-    for (int t = 0; t < NTP; ++t) bp[t] = ptrs[(size_t)p * NT + (t < NT ? t : NT - 1)];
+    for (int t = 0; t < NTP; ++t) bp[t] = (gfloat *)ptrs[(size_t)p * NT + (t < NT ? t : NT - 1)];
 
     const int c = lane & 15, g = lane >> 4;
     double accd[NACC][4];
@@ -119,13 +137,19 @@ __global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ param
 #pragma unroll
         for (int e = 0; e < 4; ++e) accd[i][e] = 0.0;
 
-    f32x4 v[NTP];
-    if (r_begin < r_end) load_block<NTP>(v, bp, r_begin, D, lane);
+    // The loads of the next block (or next two, SVDQ_PREFETCH2) are in flight while a block is computed.
+    constexpr int AHEAD = SVDQ_PREFETCH2 ? 2 : 1;
+    f32x4 v0[NTP];
+    if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
+#if SVDQ_PREFETCH2
+    f32x4 v1[NTP];
+    if (r_begin + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v1, bp, r_begin + SVDQ_BLK_ROWS, D, lane);
+#endif
 
-    for (int64_t rb = r_begin; rb < r_end; rb += SVDQ_BLK_ROWS) {
+    auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
         center_store<NTP>(v, NT, center, X, lane);
         __syncthreads();
-        if (rb + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v, bp, rb + SVDQ_BLK_ROWS, D, lane);
+        if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
 
         f32x4 acc[NACC];
 #pragma unroll
@@ -135,7 +159,7 @@ __global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ param
             const int t = c & 7;
             const bool valid = t < NTP;
             const float *xr = X + (valid ? t : 0) * XS + 16 * (c >> 3) + 4 * g;
-#pragma unroll
+UNROLL_N(SVDQ_UNROLL_GRAM)
             for (int j = 0; j < 8; ++j) {
                 f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 32 * j);
                 if (!valid) a = zero4();
@@ -143,20 +167,20 @@ __global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ param
                 for (int e = 0; e < 4; ++e) acc[0] = mfma4(a[e], a[e], acc[0]);
             }
         } else {
-            const bool v0 = c < NTP;
-            const bool v1 = (NB == 2) && (16 + c < NTP);
-            const float *x0 = X + (v0 ? c : 0) * XS + 4 * g;
-            const float *x1 = X + (v1 ? 16 + c : 0) * XS + 4 * g;
+            const bool v0ok = c < NTP;
+            const bool v1ok = (NB == 2) && (16 + c < NTP);
+            const float *x0 = X + (v0ok ? c : 0) * XS + 4 * g;
+            const float *x1 = X + (v1ok ? 16 + c : 0) * XS + 4 * g;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 f32x4 a0 = *reinterpret_cast<const f32x4 *>(x0 + 16 * j);
-                if (!v0) a0 = zero4();
+                if (!v0ok) a0 = zero4();
                 if constexpr (NB == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[0] = mfma4(a0[e], a0[e], acc[0]);
                 } else {
                     f32x4 a1 = *reinterpret_cast<const f32x4 *>(x1 + 16 * j);
-                    if (!v1) a1 = zero4();
+                    if (!v1ok) a1 = zero4();
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         acc[0] = mfma4(a0[e], a0[e], acc[0]);
@@ -171,20 +195,27 @@ __global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ param
 #pragma unroll
             for (int e = 0; e < 4; ++e) accd[i][e] += (double)acc[i][e];
         __syncthreads();
+    };
+
+    for (int64_t rb = r_begin; rb < r_end; rb += AHEAD * SVDQ_BLK_ROWS) {
+        do_block(v0, rb);
+#if SVDQ_PREFETCH2
+        if (rb + SVDQ_BLK_ROWS < r_end) do_block(v1, rb + SVDQ_BLK_ROWS);
+#endif
     }
 
     // One fp64 partial per slot, dense [NT][NT].  Lane (c,g) holds D[4g+e][c].
     const int NN = NT * NT;
     if constexpr (PACK == 2) {
         const int rs = c >> 3, n = c & 7;
-        double *dst = gram_part + ((size_t)blockIdx.x * 2 + rs) * NN;
+        double *dst = gram_part + ((size_t)uidx * 2 + rs) * NN;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int m = 4 * g + e;
             if ((m >> 3) == rs && (m & 7) < NT && n < NT) dst[(m & 7) * NT + n] = accd[0][e];
         }
     } else {
-        double *dst = gram_part + (size_t)blockIdx.x * NN;
+        double *dst = gram_part + (size_t)uidx * NN;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int m = 4 * g + e;
@@ -215,24 +246,51 @@ template <bool OUT16> struct OutT;
 template <> struct OutT<true> { using type = __half; };
 template <> struct OutT<false> { using type = float; };
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 pack_bf16(const f32x4 &lo, const f32x4 &hi) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] = (__bf16)lo[e];
+        o[4 + e] = (__bf16)hi[e];
+    }
+    return o;
+}
+
+// Projection onto the ROUNDED basis without eight more f32 MFMAs per 32 rows:
+//   c = fp16(U)^T Xc = U^T Xc + E^T Xc,   E = fp16(U) - U.
+// U^T Xc is known in closed form from the eigen-solve (sigma_i V[t][i], k_eig writes it), so only the
+// rounding correction E^T Xc -- 2^-12 of the signal -- is accumulated here, with bf16 operands on
+// v_mfma_f32_16x16x32_bf16 (K = 32 rows per instruction): bf16's 2^-9 relative operand error on a
+// 2^-12 term is 2^-21 of c, below the fp32 accumulation noise of the direct product.
 template <int NTP, bool OUT16>
 __global__ __launch_bounds__(64) void k_basis_project(
     const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
     const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
     const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
-    uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart) {
+    uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse) {
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
     constexpr int KS = NTP / 4;
     constexpr int NCB = NB * NB;
     constexpr int ES = OUT16 ? 2 : 4;
+    constexpr int TROWS = (PACK == 2) ? 32 : 16;  // rows per MFMA sub-tile
+    constexpr int NPAIR = SVDQ_BLK_ROWS / (2 * TROWS);
     using out_t = typename OutT<OUT16>::type;
 
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
-    __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP];
+    __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];  // +16: dump slot for idle lanes
 
     const int lane = threadIdx.x;
-    const SvdqUnit ud = units[blockIdx.x];
+    // units are walked in reverse when asked: pass 1 touched the LAST rows most recently, so they are
+    // the ones still resident in the Infinity Cache
+    const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    const SvdqUnit ud = units[uidx];
     const int p = ud.param;
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
     const int64_t r_begin = ud.row0;
@@ -243,13 +301,13 @@ __global__ __launch_bounds__(64) void k_basis_project(
     const int r = r_dev[p];
     const int nl = r - k;
 
-    const float *bp[NTP];
+    gfloat *bp[NTP];
 #pragma unroll
-    for (int t = 0; t < NTP; ++t) bp[t] = ptrs[(size_t)p * NT + (t < NT ? t : NT - 1)];
+    for (int t = 0; t < NTP; ++t) bp[t] = (gfloat *)ptrs[(size_t)p * NT + (t < NT ? t : NT - 1)];
 
     const int c = lane & 15, g = lane >> 4;
 
-    // W = V Sigma^-1 (columns >= r and null directions are already zero), B-operand registers.
+    // W = V Sigma^-1 (columns >= r and unresolved directions are zero), B-operand registers.
     const float *Wp = Wtab + (size_t)p * (NT * NT + 4);
     const float spike = Wp[NT * NT];
     const int nullcol = (int)Wp[NT * NT + 1];
@@ -273,8 +331,21 @@ __global__ __launch_bounds__(64) void k_basis_project(
         }
     }
 
-    out_t *OUTh = OUT;
-    out_t *OUTl = OUT + SVDQ_BLK_ROWS * k;
+    // Branch-free staging of the fp16 tile: every lane owns one U column per 16-slot block and writes
+    // it into the U_high or the U_low image; lanes without a column write to the dump slot.
+    out_t *const OUTh = OUT;
+    out_t *const OUTl = OUT + SVDQ_BLK_ROWS * k;
+    out_t *const DUMP = OUT + SVDQ_BLK_ROWS * NTP;
+    out_t *colbase[NB];
+    int colstride[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int i = (PACK == 2) ? (c & 7) : 16 * nb + c;
+        const bool valid = (PACK == 2) ? ((c & 7) < NTP && i < r) : (i < r);
+        colbase[nb] = !valid ? DUMP : (i < k ? OUTh + i : OUTl + (i - k));
+        colstride[nb] = !valid ? 0 : (i < k ? k : nl);
+    }
+
     uint8_t *slab = basis + params[p].slab_off;
     uint8_t *gUh = slab;
     uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
@@ -286,12 +357,22 @@ __global__ __launch_bounds__(64) void k_basis_project(
 #pragma unroll
         for (int e = 0; e < 4; ++e) caccd[i][e] = 0.0;
 
-    f32x4 v[NTP];
-    if (r_begin < r_end) load_block<NTP>(v, bp, r_begin, D, lane);
+    // The loads of the next block (or next two, SVDQ_PREFETCH2) are in flight while a block is computed.
+    constexpr int AHEAD = SVDQ_PREFETCH2 ? 2 : 1;
+    f32x4 v0[NTP];
+    if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
+#if SVDQ_PREFETCH2
+    f32x4 v1[NTP];
+    if (r_begin + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v1, bp, r_begin + SVDQ_BLK_ROWS, D, lane);
+#endif
 
-    for (int64_t rb = r_begin; rb < r_end; rb += SVDQ_BLK_ROWS) {
+    auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
         const f32x4 mean = center_store<NTP>(v, NT, center, X, lane);
+#ifdef SVDQ_ABLATE_STORES
+        if (gmean && D < 0) {
+#else
         if (gmean) {
+#endif
             const int64_t rr = rb + 4 * lane;
             if (rr + 3 < D) {
                 *reinterpret_cast<f32x4 *>(gmean + rr) = mean;
@@ -302,102 +383,85 @@ __global__ __launch_bounds__(64) void k_basis_project(
             }
         }
         __syncthreads();
-        if (rb + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v, bp, rb + SVDQ_BLK_ROWS, D, lane);
+        if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
 
         f32x4 cf[NCB];
 #pragma unroll
         for (int i = 0; i < NCB; ++i) cf[i] = zero4();
 
-        if constexpr (PACK == 2) {
-            const int i = c & 7;
-            const bool bvalid = i < NTP;
-            const float *xb = X + (bvalid ? i : 0) * XS + 16 * (c >> 3) + 4 * g;
+        // projection B operand ("task on slot, row on k"): per 16-slot block, which strip and rows
+        const float *xb_ptr[NB];
+        bool xb_ok[NB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f32x4 u = zero4();
+        for (int nb = 0; nb < NB; ++nb) {
+            const int t = (PACK == 2) ? (c & 7) : 16 * nb + c;
+            xb_ok[nb] = t < NTP;
+            xb_ptr[nb] = X + (xb_ok[nb] ? t : 0) * XS + ((PACK == 2) ? 16 * (c >> 3) : 0) + 4 * g;
+        }
+
+UNROLL_N(SVDQ_UNROLL_BP)
+        for (int jj = 0; jj < NPAIR; ++jj) {
+            f32x4 err[NB][2];  // E = fp16(U) - U for the two sub-tiles of this pair
+            f32x4 xb[NB][2];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const float a0 = X[(4 * s + g) * XS + 32 * j + c];
-                    const float a1 = X[(4 * s + g) * XS + 32 * j + 16 + c];
-                    u = mfma4(a0, w[s][0], u);
-                    u = mfma4(a1, whi[s], u);
-                }
-                if (j == 0 && rb == 0 && lane == i && i == nullcol) u[0] += spike;  // row 0 of the completion column
-                f32x4 uh;
-                const int row0 = 32 * j + 16 * (c >> 3) + 4 * g;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    out_t h;
-                    if constexpr (OUT16) {
-                        h = __float2half_rn(u[e]);
-                        uh[e] = __half2float(h);
-                    } else {
-                        h = u[e];
-                        uh[e] = u[e];
-                    }
-                    if (i < k)
-                        OUTh[(row0 + e) * k + i] = h;
-                    else if (i < r)
-                        OUTl[(row0 + e) * nl + (i - k)] = h;
-                }
-                f32x4 b = *reinterpret_cast<const f32x4 *>(xb + 32 * j);
-                if (!bvalid) b = zero4();
-#pragma unroll
-                for (int e = 0; e < 4; ++e) cf[0] = mfma4(uh[e], b[e], cf[0]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int j = 2 * jj + s2;
                 f32x4 u[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) u[nb] = zero4();
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    const float a = X[(4 * s + g) * XS + 16 * j + c];
+                    if constexpr (PACK == 2) {
+                        const float a0 = X[(4 * s + g) * XS + 32 * j + c];
+                        const float a1 = X[(4 * s + g) * XS + 32 * j + 16 + c];
+                        u[0] = mfma4(a0, w[s][0], u[0]);
+                        u[0] = mfma4(a1, whi[s], u[0]);
+                    } else {
+                        const float a = X[(4 * s + g) * XS + 16 * j + c];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) u[nb] = mfma4(a, w[s][nb], u[nb]);
-                }
-                if (j == 0 && rb == 0 && g == 0) {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        if (16 * nb + c == nullcol) u[nb][0] += spike;  // row 0 of the completion column
-                }
-                f32x4 uh[NB];
-                const int row0 = 16 * j + 4 * g;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int i = 16 * nb + c;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        out_t h;
-                        if constexpr (OUT16) {
-                            h = __float2half_rn(u[nb][e]);
-                            uh[nb][e] = __half2float(h);
-                        } else {
-                            h = u[nb][e];
-                            uh[nb][e] = u[nb][e];
-                        }
-                        if (i < k)
-                            OUTh[(row0 + e) * k + i] = h;
-                        else if (i < r)
-                            OUTl[(row0 + e) * nl + (i - k)] = h;
+                        for (int nb = 0; nb < NB; ++nb) u[nb] = mfma4(a, w[s][nb], u[nb]);
                     }
                 }
-                f32x4 b[NB];
+                // row 0 of the completion column (see k_eig)
+                if (j == 0 && rb == 0 && g == 0) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int i = (PACK == 2) ? c : 16 * nb + c;  // PACK: row 0 lives on slots 0-7 only
+                        if (i == nullcol) u[nb][0] += spike;
+                    }
+                }
+                const int row0 = TROWS * j + ((PACK == 2) ? 16 * (c >> 3) : 0) + 4 * g;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const int t = 16 * nb + c;
-                    const bool bv = t < NTP;
-                    b[nb] = *reinterpret_cast<const f32x4 *>(X + (bv ? t : 0) * XS + 16 * j + 4 * g);
-                    if (!bv) b[nb] = zero4();
+                    out_t *dst = colbase[nb] + row0 * colstride[nb];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (OUT16) {
+                            const __half h = __float2half_rn(u[nb][e]);
+                            dst[e * colstride[nb]] = h;
+                            err[nb][s2][e] = __half2float(h) - u[nb][e];
+                        } else {
+                            dst[e * colstride[nb]] = u[nb][e];
+                        }
+                    }
+                    if constexpr (OUT16) {
+                        xb[nb][s2] = *reinterpret_cast<const f32x4 *>(xb_ptr[nb] + TROWS * j);
+                        if (!xb_ok[nb]) xb[nb][s2] = zero4();
+                    }
+                }
+            }
+            if constexpr (OUT16) {
+                bf16x8 ea[NB], xv[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    ea[nb] = pack_bf16(err[nb][0], err[nb][1]);
+                    xv[nb] = pack_bf16(xb[nb][0], xb[nb][1]);
                 }
 #pragma unroll
                 for (int nbi = 0; nbi < NB; ++nbi)
 #pragma unroll
                     for (int nbt = 0; nbt < NB; ++nbt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            cf[nbi * NB + nbt] = mfma4(uh[nbi][e], b[nbt][e], cf[nbi * NB + nbt]);
+                        cf[nbi * NB + nbt] = mfma_bf16(ea[nbi], xv[nbt], cf[nbi * NB + nbt]);
             }
         }
 #pragma unroll
@@ -408,23 +472,34 @@ __global__ __launch_bounds__(64) void k_basis_project(
 
         // stream the two row-major output tiles of this block out of LDS, 16 B per lane
         const int rows_blk = (int)((D - rb < SVDQ_BLK_ROWS) ? (D - rb) : SVDQ_BLK_ROWS);
+#ifndef SVDQ_ABLATE_STORES
         if (k > 0) copy_out(OUTh, gUh + rb * (int64_t)k * ES, rows_blk * k * ES, lane);
         if (nl > 0) copy_out(OUTl, gUl + rb * (int64_t)nl * ES, rows_blk * nl * ES, lane);
+#else
+        if (rows_blk < 0) copy_out(OUTh, gUh, 16, lane);  // diagnostic build: keep OUT live, skip the stores
+#endif
         __syncthreads();
+    };
+
+    for (int64_t rb = r_begin; rb < r_end; rb += AHEAD * SVDQ_BLK_ROWS) {
+        do_block(v0, rb);
+#if SVDQ_PREFETCH2
+        if (rb + SVDQ_BLK_ROWS < r_end) do_block(v1, rb + SVDQ_BLK_ROWS);
+#endif
     }
 
-    // projection partials: cpart[slot][t*NT + i]; lane (c,g) holds D[m = U column][n = task]
+    // rounding-correction partials: cpart[slot][t*NT + i]; lane (c,g) holds D[m = U column][n = task]
     const int NN = NT * NT;
     if constexpr (PACK == 2) {
         const int rs = c >> 3, t = c & 7;
-        double *dst = cpart + ((size_t)blockIdx.x * 2 + rs) * NN;
+        double *dst = cpart + ((size_t)uidx * 2 + rs) * NN;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int m = 4 * g + e;
             if ((m >> 3) == rs && (m & 7) < NT && t < NT) dst[t * NT + (m & 7)] = caccd[0][e];
         }
     } else {
-        double *dst = cpart + (size_t)blockIdx.x * NN;
+        double *dst = cpart + (size_t)uidx * NN;
 #pragma unroll
         for (int nbi = 0; nbi < NB; ++nbi)
 #pragma unroll
@@ -441,24 +516,24 @@ __global__ __launch_bounds__(64) void k_basis_project(
 // ------------------------------------------------------------------------------------ launchers
 template <int NTP>
 static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                         hipStream_t st) {
-    hipLaunchKernelGGL(k_gram<NTP>, dim3(pl->n_units), dim3(64), 0, st, pl->d_params, pl->d_units,
+                         int unit0, int nunits, hipStream_t st) {
+    hipLaunchKernelGGL(k_gram<NTP>, dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units,
                        reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks, pl->cfg.center,
-                       gram_part);
+                       gram_part, unit0);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                     hipStream_t st) {
+                     int unit0, int nunits, hipStream_t st) {
     switch (pl->ntp) {
-        case 4: return launch_gram_t<4>(pl, ptrs, rows_dev, gram_part, st);
-        case 8: return launch_gram_t<8>(pl, ptrs, rows_dev, gram_part, st);
-        case 12: return launch_gram_t<12>(pl, ptrs, rows_dev, gram_part, st);
-        case 16: return launch_gram_t<16>(pl, ptrs, rows_dev, gram_part, st);
-        case 20: return launch_gram_t<20>(pl, ptrs, rows_dev, gram_part, st);
-        case 24: return launch_gram_t<24>(pl, ptrs, rows_dev, gram_part, st);
-        case 28: return launch_gram_t<28>(pl, ptrs, rows_dev, gram_part, st);
-        case 32: return launch_gram_t<32>(pl, ptrs, rows_dev, gram_part, st);
+        case 4: return launch_gram_t<4>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
+        case 8: return launch_gram_t<8>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
+        case 12: return launch_gram_t<12>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
+        case 16: return launch_gram_t<16>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
+        case 20: return launch_gram_t<20>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
+        case 24: return launch_gram_t<24>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
+        case 28: return launch_gram_t<28>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
+        case 32: return launch_gram_t<32>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
     }
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;
@@ -467,31 +542,31 @@ int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
 template <int NTP>
 static int launch_bp_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                        const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
-                       hipStream_t st) {
+                       int unit0, int nunits, int reverse, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
     if (pl->cfg.fp16)
-        hipLaunchKernelGGL((k_basis_project<NTP, true>), dim3(pl->n_units), dim3(64), 0, st, pl->d_params,
+        hipLaunchKernelGGL((k_basis_project<NTP, true>), dim3(nunits), dim3(64), 0, st, pl->d_params,
                            pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,
-                           cpart);
+                           cpart, unit0, reverse);
     else
-        hipLaunchKernelGGL((k_basis_project<NTP, false>), dim3(pl->n_units), dim3(64), 0, st, pl->d_params,
+        hipLaunchKernelGGL((k_basis_project<NTP, false>), dim3(nunits), dim3(64), 0, st, pl->d_params,
                            pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,
-                           cpart);
+                           cpart, unit0, reverse);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
-                              double *cpart, hipStream_t st) {
+                              double *cpart, int unit0, int nunits, int reverse, hipStream_t st) {
     switch (pl->ntp) {
-        case 4: return launch_bp_t<4>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
-        case 8: return launch_bp_t<8>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
-        case 12: return launch_bp_t<12>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
-        case 16: return launch_bp_t<16>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
-        case 20: return launch_bp_t<20>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
-        case 24: return launch_bp_t<24>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
-        case 28: return launch_bp_t<28>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
-        case 32: return launch_bp_t<32>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, st);
+        case 4: return launch_bp_t<4>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
+        case 8: return launch_bp_t<8>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
+        case 12: return launch_bp_t<12>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
+        case 16: return launch_bp_t<16>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
+        case 20: return launch_bp_t<20>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
+        case 24: return launch_bp_t<24>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
+        case 28: return launch_bp_t<28>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
+        case 32: return launch_bp_t<32>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
     }
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;

@@ -73,7 +73,7 @@ class CompressPlan:
 
     def __init__(self, rows: Sequence[int], n_tasks: int, *, energy_threshold: float = 0.90,
                  max_rank: Optional[int] = None, center: bool = True, fp16: bool = True,
-                 low_bits: int = 4, rtvq_stages: int = 2, device="cuda", unit_rows: int = 0):
+                 low_bits: int = 4, rtvq_stages: int = 2, device="cuda", unit_rows: int = 0, flags: int = 0):
         self.lib = nat.lib()
         self.device = resolve_device(device)
         self.rows = [int(x) for x in rows]
@@ -84,7 +84,7 @@ class CompressPlan:
         self.fp16 = bool(fp16)
         self.center = bool(center)
         self.cfg = nat.SvdqConfig(float(energy_threshold), int(max_rank) if max_rank else 0, int(bool(center)),
-                                  int(bool(fp16)), int(low_bits), int(rtvq_stages), int(unit_rows), 0)
+                                  int(bool(fp16)), int(low_bits), int(rtvq_stages), int(unit_rows), int(flags))
         self._h = c_void_p()
         rows_arr = (c_int64 * max(self.P, 1))(*self.rows)
         with torch.cuda.device(self.device):
@@ -154,6 +154,25 @@ class CompressPlan:
     def coeff_quantize(self):
         nat.check(self.lib.svdq_coeff_quantize(self._h, _ptr(self.workspace), _ptr(self.small), _stream_ptr()),
                   "svdq_coeff_quantize")
+
+    # ---- the same stages on a parameter range, on an explicit stream (for pipelined schedules)
+    def gram_range(self, table, p0, n, stream, rows_dev=None):
+        nat.check(self.lib.svdq_gram_center_range(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace), p0, n,
+                                                  c_void_p(stream.cuda_stream)), "svdq_gram_center_range")
+
+    def eig_range(self, table, p0, n, stream, rows_dev=None):
+        nat.check(self.lib.svdq_eig_rank_select_range(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace),
+                                                      _ptr(self.small), p0, n, c_void_p(stream.cuda_stream)),
+                  "svdq_eig_rank_select_range")
+
+    def bp_range(self, table, p0, n, stream, rows_dev=None):
+        nat.check(self.lib.svdq_basis_project_range(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace),
+                                                    _ptr(self.small), _ptr(self.basis), _ptr(self.mean), p0, n,
+                                                    c_void_p(stream.cuda_stream)), "svdq_basis_project_range")
+
+    def coeff_range(self, p0, n, stream):
+        nat.check(self.lib.svdq_coeff_quantize_range(self._h, _ptr(self.workspace), _ptr(self.small), p0, n,
+                                                     c_void_p(stream.cuda_stream)), "svdq_coeff_quantize_range")
 
     def run(self, table, rows_dev=None):
         """gram -> eig/rank -> basis+projection -> coefficient quantization, back to back."""

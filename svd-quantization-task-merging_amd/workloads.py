@@ -67,7 +67,7 @@ def synth_task_buffers(rows: List[int], n_tasks: int, seed: int, device, rank: i
             gt = torch.randn(rank, device=dev, generator=g)
             v = bufs[t][o:o + d]
             torch.randn(d, device=dev, generator=g, out=v)
-            v.mul_(eps).add_(B @ (gt * s), alpha=a)
+            v.mul_(eps).add_((B * (gt * s)).sum(dim=1), alpha=a)
             vs.append(v)
         views.append(vs)
         del B
