@@ -1,0 +1,94 @@
+"""
+N > 1 path on CPU: two processes over gloo (127.0.0.1).  Parameter tensors are independent units, so
+the only communication is the all-gather of the packed small-artifact buffers (ragged lengths).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import svdq_amd
+    from svdq_amd import shard, workloads
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes = workloads.vit_visual_shapes("ViT-B-32")
+        names = sorted(shapes)
+        rows = [workloads.numel(shapes[n]) for n in names]
+        parts = shard.partition_lpt(rows, world)
+        mine = parts[rank]
+        # every rank computes the same partition; shards are disjoint and cover everything
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(len(rows)))
+        # ragged "small artifact" payload: 3 bytes per owned tensor, value = tensor index
+        payload = torch.tensor([i % 251 for i in mine for _ in range(3)], dtype=torch.uint8)
+        got = shard.gather_small(payload)
+        assert len(got) == world
+        for r, buf in enumerate(got):
+            want = torch.tensor([i % 251 for i in parts[r] for _ in range(3)], dtype=torch.uint8)
+            assert torch.equal(buf, want), r
+        loads = [sum(rows[i] for i in p) for p in parts]
+        tot = torch.tensor([float(sum(rows[i] for i in mine))])
+        dist.all_reduce(tot)
+        assert int(tot.item()) == sum(rows)
+        q.put((rank, "ok", loads))
+    except Exception as e:  # surface the failure in the parent
+        q.put((rank, f"fail: {e!r}", None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_partition_and_gather():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, loads in res:
+        assert status == "ok", (rank, status)
+    loads = res[0][2]
+    assert max(loads) / min(loads) < 1.05      # LPT keeps the two shards within 5 %
+
+
+def test_partition_properties():
+    import sys
+    sys.path.insert(0, ROOT)
+    from svdq_amd import shard, workloads
+    for model, world in (("ViT-L-14", 8), ("ViT-B-16", 4), ("ViT-B-32", 3)):
+        shapes = workloads.vit_visual_shapes(model)
+        rows = [workloads.numel(shapes[n]) for n in sorted(shapes)]
+        parts = shard.partition_lpt(rows, world)
+        assert sorted(i for p in parts for i in p) == list(range(len(rows)))
+        loads = [sum(rows[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(rows)          # never worse than one tensor apart
+        assert parts == shard.partition_lpt(rows, world)     # deterministic
+    assert shard.partition_lpt([5, 3], 4) == [[0], [1], [], []]
+    # SURVEY section 8 shape totals
+    tot = {m: sum(workloads.numel(s) for s in workloads.vit_visual_shapes(m).values()) for m in workloads.VIT_SPECS}
+    assert tot == {"ViT-B-32": 87849216, "ViT-B-16": 86192640, "ViT-L-14": 303966208}
+    assert {m: len(workloads.vit_visual_shapes(m)) for m in workloads.VIT_SPECS} == \
+        {"ViT-B-32": 152, "ViT-B-16": 152, "ViT-L-14": 296}
