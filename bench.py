@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--stages", type=int, default=2)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--unit-rows", type=int, default=0)
+    ap.add_argument("--pipeline-lag", type=int, default=2, help="groups of gram issued ahead of basis_project")
+    ap.add_argument("--pipeline-in-c", action="store_true", help="run the pipelined schedule inside svdq_compress")
     ap.add_argument("--pipeline-mb", type=float, default=0.0,
                     help="experimental: group parameters into >= this many MB of input and pipeline "
                          "gram(g+1) | eig(g) on a side stream | basis_project(g) so a group's deltas are still "
@@ -153,8 +155,12 @@ def main():
     N = args.tasks
 
     bufs, views = workloads.synth_task_buffers(rows, N, seed=1234 + rank, device=dev)
+    flags = 0
+    if args.pipeline_mb > 0 and args.pipeline_in_c:
+        flags = (int(args.pipeline_mb) << 8) | ((args.pipeline_lag & 0xf) << 4)
     plan = CompressPlan(rows, N, energy_threshold=args.energy, max_rank=64, center=True, fp16=True,
-                        low_bits=args.bits, rtvq_stages=args.stages, device=dev, unit_rows=args.unit_rows)
+                        low_bits=args.bits, rtvq_stages=args.stages, device=dev, unit_rows=args.unit_rows,
+                        flags=flags)
     table = plan.pointer_table(views)
     torch.cuda.synchronize()
 
@@ -162,7 +168,7 @@ def main():
 
     # optional pipelined schedule over groups of consecutive parameters
     groups = []
-    if args.pipeline_mb > 0:
+    if args.pipeline_mb > 0 and not args.pipeline_in_c:
         p0, acc = 0, 0.0
         for i, d in enumerate(rows):
             acc += d * N * 4 / 1e6
@@ -173,17 +179,28 @@ def main():
     gev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in groups]
 
     def step_pipelined():
+        """G(0..lag) | then per group: eig(g) on the side stream as soon as gram(g) is done, gram(g+lag+1) on the
+        main stream, basis_project(g) once eig(g) has finished.  eig(g) therefore has lag grams and lag-1
+        basis_projects of other groups to hide behind."""
         main = torch.cuda.current_stream()
-        G = len(groups)
-        plan.gram_range(table, *groups[0], main)
-        gev[0][0].record(main)
-        for g in range(G):
+        G, lag = len(groups), max(1, args.pipeline_lag)
+        issued = 0
+
+        def issue_gram():
+            nonlocal issued
+            g = issued
+            plan.gram_range(table, *groups[g], main)
+            gev[g][0].record(main)
             side.wait_event(gev[g][0])
             plan.eig_range(table, *groups[g], side)
             gev[g][1].record(side)
-            if g + 1 < G:
-                plan.gram_range(table, *groups[g + 1], main)
-                gev[g + 1][0].record(main)
+            issued += 1
+
+        for _ in range(min(lag, G)):
+            issue_gram()
+        for g in range(G):
+            if issued < G:
+                issue_gram()
             main.wait_event(gev[g][1])
             plan.bp_range(table, *groups[g], main)
         plan.coeff_range(0, len(rows), main)
@@ -191,7 +208,7 @@ def main():
     def step(events=None):
         if groups:
             step_pipelined()
-        elif events is None:
+        elif events is None or args.pipeline_in_c:
             plan.run(table)
         else:
             events[0].record(); plan.gram_center(table)
@@ -227,7 +244,7 @@ def main():
 
     # per-kernel HIP-event times (this rank), averaged over the timed steps
     kms = [0.0] * 4
-    if not groups:
+    if not groups and not args.pipeline_in_c:
         for s in range(args.steps):
             for i in range(4):
                 kms[i] += ev[s][i].elapsed_time(ev[s][i + 1])

@@ -50,7 +50,8 @@ typedef struct svdq_config {
     int32_t low_bits;          /* svd_low_bits 1..8                                  */
     int32_t rtvq_stages;       /* svd_rtvq_stages 1..SVDQ_MAX_STAGES                 */
     int32_t unit_rows;         /* 0 = auto; rows per work unit (multiple of 256)     */
-    int32_t reserved;
+    int32_t reserved;          /* schedule bits, 0 = four whole-batch launches.  bits 8..23: group size in MB for
+                                  the cache-resident pipeline of svdq_compress; bits 4..7: its lag (default 2)  */
 } svdq_config;
 
 /* Byte sizes / strides the caller needs to allocate outputs (all device memory). */

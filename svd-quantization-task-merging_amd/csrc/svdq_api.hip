@@ -135,6 +135,10 @@ extern "C" int svdq_plan_create(svdq_plan **out, int32_t n_tasks, int32_t n_para
     off += svdq_align_up((int64_t)n_params * (nn + 4) * 4, 256);  // W [N][N] + {spike, null column, -, -}
     pl->ws_c0_off = off;
     off += svdq_align_up((int64_t)n_params * nn * 8, 256);        // closed-form coefficients of the unrounded basis
+    pl->ws_gram2_off = off;
+    off += svdq_align_up((int64_t)n_params * SVDQ_RC * nn * 8, 256);  // level-2 partials (k_reduce)
+    pl->ws_cpart2_off = off;
+    off += svdq_align_up((int64_t)n_params * SVDQ_RC * nn * 8, 256);
     pl->sizes.workspace_bytes = off;
     pl->sizes.basis_bytes = basis_bytes;
     pl->sizes.mean_floats = mean_floats;
@@ -159,6 +163,45 @@ extern "C" int svdq_plan_create(svdq_plan **out, int32_t n_tasks, int32_t n_para
     L.total_bytes = off;
     pl->sizes.small_bytes = off;
 
+    // cache-resident pipeline: groups of consecutive parameters with >= group_mb MB of input
+    const int group_mb = (cfg->reserved >> 8) & 0xffff;
+    pl->lag = (cfg->reserved >> 4) & 0xf;
+    if (pl->lag < 1) pl->lag = 2;
+    if (group_mb > 0) {
+        pl->grp_p0 = (int32_t *)calloc(n_params, sizeof(int32_t));
+        pl->grp_n = (int32_t *)calloc(n_params, sizeof(int32_t));
+        int p0 = 0;
+        double acc = 0.0;
+        for (int p = 0; p < n_params; ++p) {
+            acc += (double)rows[p] * N * 4.0 / 1e6;
+            if (acc >= group_mb || p == n_params - 1) {
+                pl->grp_p0[pl->n_groups] = p0;
+                pl->grp_n[pl->n_groups] = p + 1 - p0;
+                ++pl->n_groups;
+                p0 = p + 1;
+                acc = 0.0;
+            }
+        }
+        pl->ev_gram = (hipEvent_t *)calloc(pl->n_groups, sizeof(hipEvent_t));
+        pl->ev_eig = (hipEvent_t *)calloc(pl->n_groups, sizeof(hipEvent_t));
+        pl->ev_bp = (hipEvent_t *)calloc(pl->n_groups, sizeof(hipEvent_t));
+        hipError_t ee = hipSuccess;
+        for (int i = 0; i < SVDQ_NSIDE && ee == hipSuccess; ++i)
+            ee = hipStreamCreateWithFlags(&pl->side[i], hipStreamNonBlocking);
+        for (int g = 0; g < pl->n_groups && ee == hipSuccess; ++g) {
+            ee = hipEventCreateWithFlags(&pl->ev_gram[g], hipEventDisableTiming);
+            if (ee == hipSuccess) ee = hipEventCreateWithFlags(&pl->ev_eig[g], hipEventDisableTiming);
+            if (ee == hipSuccess) ee = hipEventCreateWithFlags(&pl->ev_bp[g], hipEventDisableTiming);
+        }
+        if (ee == hipSuccess) ee = hipEventCreateWithFlags(&pl->ev_start, hipEventDisableTiming);
+        if (ee == hipSuccess) ee = hipStreamCreateWithFlags(&pl->gram_stream, hipStreamNonBlocking);
+        if (ee != hipSuccess) {
+            svdq_set_error("pipeline stream/event creation failed: %s", hipGetErrorString(ee));
+            svdq_plan_destroy(pl);
+            return SVDQ_EHIP;
+        }
+    }
+
     hipError_t e = hipMalloc((void **)&pl->d_params, sizeof(SvdqParam) * n_params);
     if (e == hipSuccess) e = hipMalloc((void **)&pl->d_units, sizeof(SvdqUnit) * n_units);
     if (e == hipSuccess)
@@ -177,6 +220,20 @@ extern "C" void svdq_plan_destroy(svdq_plan *pl) {
     if (!pl) return;
     if (pl->d_params) (void)hipFree(pl->d_params);
     if (pl->d_units) (void)hipFree(pl->d_units);
+    for (int g = 0; g < pl->n_groups; ++g) {
+        if (pl->ev_gram && pl->ev_gram[g]) (void)hipEventDestroy(pl->ev_gram[g]);
+        if (pl->ev_eig && pl->ev_eig[g]) (void)hipEventDestroy(pl->ev_eig[g]);
+        if (pl->ev_bp && pl->ev_bp[g]) (void)hipEventDestroy(pl->ev_bp[g]);
+    }
+    if (pl->ev_start) (void)hipEventDestroy(pl->ev_start);
+    if (pl->gram_stream) (void)hipStreamDestroy(pl->gram_stream);
+    free(pl->ev_bp);
+    for (int i = 0; i < SVDQ_NSIDE; ++i)
+        if (pl->side[i]) (void)hipStreamDestroy(pl->side[i]);
+    free(pl->grp_p0);
+    free(pl->grp_n);
+    free(pl->ev_gram);
+    free(pl->ev_eig);
     free(pl->h_params);
     free(pl->h_units);
     free(pl);
@@ -240,7 +297,11 @@ extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs,
         return SVDQ_EINVAL;
     }
     if (int rc = check_range(pl, param0, nparams)) return rc;
-    return svdq_launch_eig(pl, ptrs, rows_dev, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram_off)),
+    if (int rc = svdq_launch_reduce(pl, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram_off)),
+                                    reinterpret_cast<double *>(ws(workspace, pl->ws_gram2_off)), param0, nparams,
+                                    (hipStream_t)stream))
+        return rc;
+    return svdq_launch_eig(pl, ptrs, rows_dev, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram2_off)),
                            reinterpret_cast<float *>(ws(workspace, pl->ws_w_off)),
                            reinterpret_cast<double *>(ws(workspace, pl->ws_c0_off)), reinterpret_cast<uint8_t *>(small),
                            param0, nparams, (hipStream_t)stream);
@@ -276,7 +337,11 @@ extern "C" int svdq_coeff_quantize_range(const svdq_plan *pl, void *workspace, v
         return SVDQ_EINVAL;
     }
     if (int rc = check_range(pl, param0, nparams)) return rc;
-    return svdq_launch_coeff(pl, reinterpret_cast<const double *>(ws(workspace, pl->ws_cpart_off)),
+    if (int rc = svdq_launch_reduce(pl, reinterpret_cast<const double *>(ws(workspace, pl->ws_cpart_off)),
+                                    reinterpret_cast<double *>(ws(workspace, pl->ws_cpart2_off)), param0, nparams,
+                                    (hipStream_t)stream))
+        return rc;
+    return svdq_launch_coeff(pl, reinterpret_cast<const double *>(ws(workspace, pl->ws_cpart2_off)),
                              reinterpret_cast<const double *>(ws(workspace, pl->ws_c0_off)),
                              reinterpret_cast<uint8_t *>(small), param0, nparams, (hipStream_t)stream);
 }
@@ -304,8 +369,42 @@ extern "C" int svdq_coeff_quantize(const svdq_plan *pl, void *workspace, void *s
     return svdq_coeff_quantize_range(pl, workspace, small, 0, pl->n_params, stream);
 }
 
+// Cache-resident schedule over groups of consecutive parameters (>= group_mb MB of deltas each):
+//   gram stream   : gram(0) gram(1) ...            gram(g) waits for bp(g - lag)  (back-pressure)
+//   side streams  : eig(g) as soon as gram(g) is done (independent solves, dealt over SVDQ_NSIDE streams)
+//   caller stream : bp(g) as soon as eig(g) is done, finally the coefficient epilogue
+// Two streaming kernels (one gram, one basis_project) are in flight at any time, so the ramp and tail
+// of per-group launches overlap, and basis_project(g) runs while group g's deltas are still (mostly)
+// resident in the 256 MiB Infinity Cache.  Everything is joined back into the caller's stream.
+static int compress_pipelined(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                              void *small, void *basis, float *mean, hipStream_t main) {
+    const int G = pl->n_groups;
+    HIP_TRY(hipEventRecord(pl->ev_start, main));
+    HIP_TRY(hipStreamWaitEvent(pl->gram_stream, pl->ev_start, 0));
+    for (int i = 0; i < SVDQ_NSIDE; ++i) HIP_TRY(hipStreamWaitEvent(pl->side[i], pl->ev_start, 0));
+    for (int g = 0; g < G; ++g) {
+        if (g >= pl->lag) HIP_TRY(hipStreamWaitEvent(pl->gram_stream, pl->ev_bp[g - pl->lag], 0));
+        int rc = svdq_gram_center_range(pl, ptrs, rows_dev, workspace, pl->grp_p0[g], pl->grp_n[g], pl->gram_stream);
+        if (rc != SVDQ_OK) return rc;
+        HIP_TRY(hipEventRecord(pl->ev_gram[g], pl->gram_stream));
+        hipStream_t sd = pl->side[g % SVDQ_NSIDE];
+        HIP_TRY(hipStreamWaitEvent(sd, pl->ev_gram[g], 0));
+        rc = svdq_eig_rank_select_range(pl, ptrs, rows_dev, workspace, small, pl->grp_p0[g], pl->grp_n[g], sd);
+        if (rc != SVDQ_OK) return rc;
+        HIP_TRY(hipEventRecord(pl->ev_eig[g], sd));
+        HIP_TRY(hipStreamWaitEvent(main, pl->ev_eig[g], 0));
+        rc = svdq_basis_project_range(pl, ptrs, rows_dev, workspace, small, basis, mean, pl->grp_p0[g], pl->grp_n[g],
+                                      main);
+        if (rc != SVDQ_OK) return rc;
+        HIP_TRY(hipEventRecord(pl->ev_bp[g], main));
+    }
+    return svdq_coeff_quantize(pl, workspace, small, main);
+}
+
 extern "C" int svdq_compress(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
                              void *small, void *basis, float *mean, void *stream) {
+    if (pl && pl->n_groups > 1)
+        return compress_pipelined(pl, ptrs, rows_dev, workspace, small, basis, mean, (hipStream_t)stream);
     int rc = svdq_gram_center(pl, ptrs, rows_dev, workspace, stream);
     if (rc == SVDQ_OK) rc = svdq_eig_rank_select(pl, ptrs, rows_dev, workspace, small, stream);
     if (rc == SVDQ_OK) rc = svdq_basis_project(pl, ptrs, rows_dev, workspace, small, basis, mean, stream);

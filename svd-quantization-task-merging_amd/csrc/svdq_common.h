@@ -15,6 +15,8 @@
 #include "../../include/svdq.h"
 
 #define SVDQ_BLK_ROWS 256
+#define SVDQ_NSIDE 4  // side streams the per-group eigen-solves are dealt over
+#define SVDQ_RC 16  // level-2 partial chunks per parameter (k_reduce)
 #ifndef SVDQ_XS
 #define SVDQ_XS 260  // LDS row stride (floats) of one task's 256-row strip: 256 + pad, multiple of 4 (16-B alignment)
 #endif
@@ -41,13 +43,19 @@ struct svdq_plan {
     svdq_sizes sizes;
     svdq_small_layout small;
     // workspace offsets (bytes)
-    int64_t ws_gram_off, ws_cpart_off, ws_w_off, ws_c0_off;
+    int64_t ws_gram_off, ws_cpart_off, ws_w_off, ws_c0_off, ws_gram2_off, ws_cpart2_off;
     // host copies
     SvdqParam *h_params;
     SvdqUnit *h_units;
     // device tables
     SvdqParam *d_params;
     SvdqUnit *d_units;
+    // optional cache-resident pipeline (cfg.reserved bits 8..23 = group size in MB, bits 4..7 = lag)
+    int32_t n_groups, lag;
+    int32_t *grp_p0, *grp_n;
+    hipEvent_t *ev_gram, *ev_eig, *ev_bp, ev_start;
+    hipStream_t gram_stream;
+    hipStream_t side[SVDQ_NSIDE];
 };
 
 __host__ __device__ static inline int64_t svdq_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -65,5 +73,7 @@ int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64
                               double *cpart, int unit0, int nunits, int reverse, hipStream_t st);
 int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W,
                     double *c0, uint8_t *small, int param0, int nparams, hipStream_t st);
+int svdq_launch_reduce(const svdq_plan *pl, const double *part, double *part2, int param0, int nparams,
+                       hipStream_t st);
 int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, const double *c0, uint8_t *small, int param0,
                       int nparams, hipStream_t st);

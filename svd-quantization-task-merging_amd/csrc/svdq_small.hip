@@ -37,141 +37,219 @@ __device__ void reduce_partials(const double *__restrict__ part, int s0, int s1,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict__ params,
-                                                     const float *const *__restrict__ ptrs,
-                                                     const int64_t *__restrict__ rows_dev, int NT, int pack,
-                                                     int center, float thr, int max_rank, const double *__restrict__ gram_part,
-                                                     float *__restrict__ Wtab, double *__restrict__ c0_out, int param0,
-                                                     float *__restrict__ sigma_out,
-                                                     int32_t *__restrict__ k_out, int32_t *__restrict__ r_out,
-                                                     float *__restrict__ energy_out, int64_t *__restrict__ rows_out) {
+// First-level reduction, spread over the chip: chunk c of parameter p sums its share of the unit
+// slots (fixed order inside the chunk) into part2[(p*SVDQ_RC + c)][nn]; k_eig / k_coeff then only add
+// SVDQ_RC partials per parameter.  Keeps the whole reduction deterministic and off one CU.
+__global__ __launch_bounds__(EIG_THREADS) void k_reduce(const SvdqParam *__restrict__ params, int NT, int pack,
+                                                        const double *__restrict__ part, double *__restrict__ part2,
+                                                        int param0) {
     __shared__ double red[4 * 1024];
-    __shared__ double G[1024];
-    __shared__ double Gd[1024];
-    __shared__ double xc0[32];
-    __shared__ int s_i0;
-    __shared__ double s_spike;
-    __shared__ double A[32 * LDN];
-    __shared__ double V[32 * LDN];
-    __shared__ double lam[32];
-    __shared__ double rowoff[32];
-    __shared__ int order[32];
-    __shared__ double sgn[32];
-    __shared__ double sig[32];
-    __shared__ int done;
-    __shared__ int pr_p[16], pr_q[16];
-    __shared__ double pr_c[16], pr_s[16];
-
-    const int p = param0 + blockIdx.x, tid = threadIdx.x, n = NT;
+    __shared__ double out[1024];
+    const int p = param0 + blockIdx.x, c = blockIdx.y, nn = NT * NT;
     const SvdqParam pd = params[p];
-    const int64_t D = rows_dev ? rows_dev[p] : pd.rows;
-    reduce_partials(gram_part, pd.unit_begin * pack, (pd.unit_begin + pd.unit_count) * pack, n * n, red, G);
+    const int s0 = pd.unit_begin * pack, ns = pd.unit_count * pack;
+    const int per = (ns + SVDQ_RC - 1) / SVDQ_RC;
+    int a = s0 + c * per, b = a + per;
+    if (b > s0 + ns) b = s0 + ns;
+    if (a > b) a = b;
+    reduce_partials(part, a, b, nn, red, out);
+    for (int e = threadIdx.x; e < nn; e += EIG_THREADS) part2[((size_t)p * SVDQ_RC + c) * nn + e] = out[e];
+}
 
-    // Centred rows sum to zero, so 1/sqrt(N) is an exact null vector of Tc.  The fp32-product Gram
-    // only resolves sigma down to ~1e-4 sigma_0, so deflate that direction explicitly in fp64:
+int svdq_launch_reduce(const svdq_plan *pl, const double *part, double *part2, int param0, int nparams,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce, dim3(nparams, SVDQ_RC), dim3(EIG_THREADS), 0, st, pl->d_params, pl->n_tasks, pl->pack,
+                       part, part2, param0);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+// Rotation (c, s) that annihilates a_pq.  The ANGLE only has to be good enough to make the sweep
+// converge (it is seeded in fp32: one v_rcp/v_sqrt instead of two fp64 divides and two fp64 square
+// roots on the critical path of every round); ORTHOGONALITY must hold to fp64, so c = (1+t^2)^-1/2 is
+// refined by Newton steps in fp64 and s = t c.
+__device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double &cs, double &sn) {
+    cs = 1.0;
+    sn = 0.0;
+    if (apq == 0.0) return;
+    const float o = (float)(2.0 * apq);
+    const float d = (float)(aqq - app);
+    double td;
+    if (o != 0.f && fabsf(d) < 3.0e38f) {
+        // 1-ulp hardware approximations are plenty for the angle
+        const float tau = d * __builtin_amdgcn_rcpf(o);
+        const float at = fabsf(tau);
+        const float t = (at > 1.0e18f) ? 0.5f * __builtin_amdgcn_rcpf(at)
+                                       : __builtin_amdgcn_rcpf(at + __builtin_amdgcn_sqrtf(1.0f + at * at));
+        td = (double)(tau >= 0.f ? t : -t);
+    } else {  // fp32 under/overflow of the operands: the slow exact path (rare)
+        const double tau = (aqq - app) / (2.0 * apq);
+        td = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    }
+    const double x = 1.0 + td * td;  // in [1, 2]
+    double r = (double)__builtin_amdgcn_rsqf((float)x);  // ~1e-7; two Newton steps -> fp64
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    cs = r;
+    sn = td * r;
+}
+
+// One-wavefront workgroups need no s_barrier: LDS operations of a wave execute in order, so only the
+// compiler has to be kept from moving accesses across the phase boundary.
+template <int THREADS>
+__device__ __forceinline__ void phase_sync() {
+    if constexpr (THREADS == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// THREADS = 64 for n <= 8 (one wavefront: barriers cost nothing), 256 otherwise.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_eig(const SvdqParam *__restrict__ params,
+                                                 const float *const *__restrict__ ptrs,
+                                                 const int64_t *__restrict__ rows_dev, int NT, int center, float thr,
+                                                 int max_rank, const double *__restrict__ gram_part2,
+                                                 float *__restrict__ Wtab, double *__restrict__ c0_out, int param0,
+                                                 float *__restrict__ sigma_out, int32_t *__restrict__ k_out,
+                                                 int32_t *__restrict__ r_out, float *__restrict__ energy_out,
+                                                 int64_t *__restrict__ rows_out) {
+    __shared__ double Gd[1024];        // (deflated) Gram, kept for the completion column
+    __shared__ double A[32 * LDN];     // working matrix, later W in fp64
+    __shared__ double V[32 * LDN];
+    __shared__ double lam[32], rowoff[32], rowdg[32], sgn[32], sig[32], xc0[32], u0[32];
+    __shared__ int order[32];
+    __shared__ int s_i0;
+
+    const int p = param0 + blockIdx.x, tid = threadIdx.x, n = NT, nn = NT * NT;
+    const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
+
+    // fixed-order sum of the SVDQ_RC level-2 partials
+    for (int e = tid; e < nn; e += THREADS) {
+        const double *src = gram_part2 + (size_t)p * SVDQ_RC * nn + e;
+        double a = 0.0;
+#pragma unroll
+        for (int c = 0; c < SVDQ_RC; ++c) a += src[(size_t)c * nn];
+        Gd[e] = a;
+    }
+    __syncthreads();
+
+    // Centred rows sum to zero, so 1/sqrt(N) is an exact null vector of Tc.  The fp32-product Gram only
+    // resolves sigma down to ~1e-4 sigma_0, so deflate that direction explicitly in fp64:
     // G <- C G C, C = I - 11^T/N.  (LAPACK reports ~1e-7 sigma_0 noise there; we report ~0.)
     if (center) {
         if (tid < n) {
-            double s = 0.0;
-            for (int j = 0; j < n; ++j) s += 0.5 * (G[tid * n + j] + G[j * n + tid]);
-            rowoff[tid] = s / n;
+            double sm = 0.0;
+            for (int j = 0; j < n; ++j) sm += 0.5 * (Gd[tid * n + j] + Gd[j * n + tid]);
+            rowoff[tid] = sm / n;
         }
         __syncthreads();
-        if (tid == 0) {
-            double s = 0.0;
-            for (int j = 0; j < n; ++j) s += rowoff[j];
-            lam[0] = s / n;
+        double tot = 0.0;
+        for (int j = 0; j < n; ++j) tot += rowoff[j];
+        tot /= n;
+        for (int e = tid; e < nn; e += THREADS) {
+            const int i = e / n, j = e % n;
+            A[i * LDN + j] = 0.5 * (Gd[i * n + j] + Gd[j * n + i]) - rowoff[i] - rowoff[j] + tot;
         }
-        __syncthreads();
+    } else {
+        for (int e = tid; e < nn; e += THREADS) {
+            const int i = e / n, j = e % n;
+            A[i * LDN + j] = 0.5 * (Gd[i * n + j] + Gd[j * n + i]);
+        }
     }
-    for (int e = tid; e < n * n; e += EIG_THREADS) {
+    __syncthreads();
+    for (int e = tid; e < nn; e += THREADS) {
         const int i = e / n, j = e % n;
-        // G is symmetric by construction (same products, same order); average anyway.
-        double a = 0.5 * (G[i * n + j] + G[j * n + i]);
-        if (center) a = a - rowoff[i] - rowoff[j] + lam[0];
-        Gd[i * n + j] = a;  // deflated Gram, kept for the completion column's coefficients
-        A[i * LDN + j] = a;
+        Gd[e] = A[i * LDN + j];
         V[i * LDN + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
 
     // Parallel-order cyclic Jacobi: a round-robin tournament pairs all indices into M = ceil(n/2)
-    // disjoint (p,q) per round (n_even - 1 rounds per sweep); the M rotations of a round commute, so
-    // they are applied together: A <- A J (columns), then A <- J^T A (rows), V <- V J.
-    // 3 barriers per ROUND instead of 2 per rotation: ~5x less latency at n = 8, ~10x at n = 32.
+    // disjoint (p,q) per round (ne - 1 rounds per sweep); the M rotations of a round commute, so they
+    // are applied together: A <- A J (columns), then A <- J^T A (rows), V <- V J.
     const int M = (n + 1) >> 1, ne = 2 * M;
-    for (int sweep = 0; sweep < 40; ++sweep) {
+    // fixed work assignment: item e = (idx, m) -> thread e % THREADS; n*M <= 512, so <= 2 items/thread
+    // for THREADS = 256 and exactly <= 1 for THREADS = 64 (n <= 8).  No division inside the sweeps.
+    constexpr int ITEMS = (THREADS == 64) ? 1 : 2;
+    int it_idx[ITEMS], it_m[ITEMS];
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+        const int e = tid + u * THREADS;
+        it_idx[u] = (e < n * M) ? e / M : -1;
+        it_m[u] = (e < n * M) ? e % M : 0;
+    }
+    for (int sweep = 0; sweep < 40 && n >= 2; ++sweep) {
         if (tid < n) {
             double off = 0.0;
-            for (int j = 0; j < n; ++j)
-                if (j != tid) off += A[tid * LDN + j] * A[tid * LDN + j];
-            rowoff[tid] = off;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double off = 0.0, dg = 0.0;
             for (int j = 0; j < n; ++j) {
-                off += rowoff[j];
-                dg += A[j * LDN + j] * A[j * LDN + j];
+                const double a = A[tid * LDN + j];
+                off += (j != tid) ? a * a : 0.0;
             }
-            done = (off <= 1e-30 * dg) || (dg == 0.0);
+            rowoff[tid] = off;
+            rowdg[tid] = A[tid * LDN + tid] * A[tid * LDN + tid];
         }
-        __syncthreads();
-        if (done || n < 2) break;
+        phase_sync<THREADS>();
+        double off = 0.0, dg = 0.0;  // every thread adds the n row sums in the same order: uniform decision
+        for (int j = 0; j < n; ++j) {
+            off += rowoff[j];
+            dg += rowdg[j];
+        }
+        if (off <= 1e-30 * dg || dg == 0.0) break;
         for (int rd = 0; rd < ne - 1; ++rd) {
-            if (tid < M) {
-                int a, b;
-                if (tid == 0) {
-                    a = ne - 1;
-                    b = rd;
+            // every thread derives the rotation of ITS pair itself (same inputs -> same bits in all of
+            // the pair's threads) and keeps (c, s) in registers for the column and the row phase
+            int pp[ITEMS], qq[ITEMS];
+            double cs[ITEMS], sn[ITEMS];
+#pragma unroll
+            for (int u = 0; u < ITEMS; ++u) {
+                const int m = it_m[u];
+                int a2, b2;
+                if (m == 0) {
+                    a2 = ne - 1;
+                    b2 = rd;
                 } else {
-                    a = (rd + tid) % (ne - 1);
-                    b = (rd - tid + (ne - 1)) % (ne - 1);
+                    a2 = rd + m;
+                    if (a2 >= ne - 1) a2 -= ne - 1;
+                    b2 = rd - m;
+                    if (b2 < 0) b2 += ne - 1;
                 }
-                const int pp = a < b ? a : b, q = a < b ? b : a;
-                double cs = 1.0, sn = 0.0;
-                if (q < n) {
-                    const double app = A[pp * LDN + pp], aqq = A[q * LDN + q], apq = A[pp * LDN + q];
-                    if (apq != 0.0) {
-                        const double tau = (aqq - app) / (2.0 * apq);
-                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                        cs = 1.0 / sqrt(1.0 + t * t);
-                        sn = t * cs;
-                    }
-                }
-                pr_p[tid] = pp;
-                pr_q[tid] = q;
-                pr_c[tid] = cs;
-                pr_s[tid] = sn;
+                pp[u] = a2 < b2 ? a2 : b2;
+                qq[u] = a2 < b2 ? b2 : a2;
+                cs[u] = 1.0;
+                sn[u] = 0.0;
+                if (it_idx[u] >= 0 && qq[u] < n)
+                    jacobi_cs(A[pp[u] * LDN + pp[u]], A[qq[u] * LDN + qq[u]], A[pp[u] * LDN + qq[u]], cs[u], sn[u]);
             }
-            __syncthreads();
-            for (int e = tid; e < n * M; e += EIG_THREADS) {  // columns of A and V
-                const int i = e / M, m = e % M;
-                const int pp = pr_p[m], q = pr_q[m];
-                if (q < n) {
-                    const double cs = pr_c[m], sn = pr_s[m];
-                    const double x = A[i * LDN + pp], y = A[i * LDN + q];
-                    A[i * LDN + pp] = cs * x - sn * y;
-                    A[i * LDN + q] = sn * x + cs * y;
-                    const double vx = V[i * LDN + pp], vy = V[i * LDN + q];
-                    V[i * LDN + pp] = cs * vx - sn * vy;
-                    V[i * LDN + q] = sn * vx + cs * vy;
+            phase_sync<THREADS>();  // everybody has read the 2x2 blocks before anybody rotates
+#pragma unroll
+            for (int u = 0; u < ITEMS; ++u) {  // columns of A and V: A <- A J, V <- V J
+                const int i = it_idx[u];
+                if (i >= 0 && qq[u] < n) {
+                    const double x = A[i * LDN + pp[u]], y = A[i * LDN + qq[u]];
+                    A[i * LDN + pp[u]] = cs[u] * x - sn[u] * y;
+                    A[i * LDN + qq[u]] = sn[u] * x + cs[u] * y;
+                    const double vx = V[i * LDN + pp[u]], vy = V[i * LDN + qq[u]];
+                    V[i * LDN + pp[u]] = cs[u] * vx - sn[u] * vy;
+                    V[i * LDN + qq[u]] = sn[u] * vx + cs[u] * vy;
                 }
             }
-            __syncthreads();
-            for (int e = tid; e < n * M; e += EIG_THREADS) {  // rows of A
-                const int j = e / M, m = e % M;
-                const int pp = pr_p[m], q = pr_q[m];
-                if (q < n) {
-                    const double cs = pr_c[m], sn = pr_s[m];
-                    const double x = A[pp * LDN + j], y = A[q * LDN + j];
-                    A[pp * LDN + j] = (j == q) ? 0.0 : cs * x - sn * y;
-                    A[q * LDN + j] = (j == pp) ? 0.0 : sn * x + cs * y;
+            phase_sync<THREADS>();
+#pragma unroll
+            for (int u = 0; u < ITEMS; ++u) {  // rows of A: A <- J^T A
+                const int j = it_idx[u];
+                if (j >= 0 && qq[u] < n) {
+                    const double x = A[pp[u] * LDN + j], y = A[qq[u] * LDN + j];
+                    A[pp[u] * LDN + j] = cs[u] * x - sn[u] * y;
+                    A[qq[u] * LDN + j] = sn[u] * x + cs[u] * y;
                 }
             }
-            __syncthreads();
+            phase_sync<THREADS>();
         }
     }
+    __syncthreads();
 
     // sort descending (stable on ties), sign convention: largest-|v| component positive
     if (tid < n) lam[tid] = A[tid * LDN + tid];
@@ -228,84 +306,84 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(const SvdqParam *__restrict
         r_out[p] = r;
         energy_out[p] = (kk > 0 && r > 0) ? cum[kk - 1] : 0.f;
         rows_out[p] = D;
-    }
-    // W[t][i] = sgn_i V[t][order[i]] / sigma_i.  Directions with sigma_i <= 1e-6 sigma_0 are below the
-    // fp32 resolution of the data (LAPACK returns an arbitrary unit vector orthogonal to the rest
-    // there).  The first such direction -- the one centring always creates -- gets an explicit
-    // orthonormal completion u = (e_0 - U U[0,:]^T) / norm, i.e. one more W column
-    // w[t] = -(sum_j W[t][j] U[0][j]) / norm plus a spike 1/norm at row 0 (added in pass 2);
-    // any further null directions are zero columns ("null directions").
-    const double s0 = sig[0];
-    for (int e = tid; e < n * n; e += EIG_THREADS) {
-        const int t = e / n, i = e % n;
-        double wv = 0.0;
-        if (i < r && sig[i] > 1e-6 * s0 && sig[i] > 0.0) wv = sgn[i] * V[t * LDN + order[i]] / sig[i];
-        A[t * LDN + i] = wv;  // A is free after the sweeps
-    }
-    float *aux = Wtab + (size_t)p * (n * n + 4) + n * n;
-    if (tid < n && D > 0) lam[tid] = (double)ptrs[(size_t)p * n + tid][0];  // row 0 of every task
-    __syncthreads();
-    if (tid == 0) {
+        // first direction below the fp32 resolution of the data, if any
         int i0 = -1;
-        if (s0 > 0.0 && D > 0)
+        if (sig[0] > 0.0 && D > 0)
             for (int i = 0; i < r; ++i)
-                if (!(sig[i] > 1e-6 * s0)) {
+                if (!(sig[i] > 1e-6 * sig[0])) {
                     i0 = i;
                     break;
                 }
-        float spike = 0.f;
-        if (i0 >= 0) {
-            // centre row 0 exactly as the streaming kernels do (fp32, task order, one divide)
-            float sum = 0.f;
-            for (int t = 0; t < n; ++t) sum += (float)lam[t];
-            const float mean0 = center ? sum / (float)n : 0.f;
-            double norm2 = 1.0;
-            for (int t = 0; t < n; ++t) xc0[t] = (double)((float)lam[t] - mean0);
-            for (int j = 0; j < r; ++j) {
-                double u = 0.0;
-                for (int t = 0; t < n; ++t) u += xc0[t] * A[t * LDN + j];
-                rowoff[j] = u;  // U[0][j]
-                norm2 -= u * u;
-            }
-            if (norm2 > 0.25) {
-                const double inv = 1.0 / sqrt(norm2);
-                for (int t = 0; t < n; ++t) {
-                    double acc = 0.0;
-                    for (int j = 0; j < r; ++j) acc += A[t * LDN + j] * rowoff[j];
-                    lam[t] = -inv * acc;  // lam (row 0 of the tasks) is already folded into xc0
-                }
-                for (int t = 0; t < n; ++t) A[t * LDN + i0] = lam[t];
-                spike = (float)inv;
-            } else {
-                i0 = -1;
-            }
-        }
-        aux[0] = spike;
-        aux[1] = (float)i0;
-        aux[2] = 0.f;
-        aux[3] = 0.f;
         s_i0 = i0;
-        s_spike = (double)spike;
+    }
+    // W[t][i] = sgn_i V[t][order[i]] / sigma_i for the resolved directions, 0 otherwise (A is free now)
+    const double s0 = sig[0];
+    for (int e = tid; e < nn; e += THREADS) {
+        const int t = e / n, i = e % n;
+        double wv = 0.0;
+        if (i < r && sig[i] > 1e-6 * s0 && sig[i] > 0.0) wv = sgn[i] * V[t * LDN + order[i]] / sig[i];
+        A[t * LDN + i] = wv;
+    }
+    if (tid < n && D > 0) lam[tid] = (double)ptrs[(size_t)p * n + tid][0];  // row 0 of every task
+    __syncthreads();
+
+    // Orthonormal completion of the first null direction (the one centring always creates; LAPACK
+    // returns an arbitrary orthonormal vector there): u = (e_0 - U U[0,:]^T) / norm, i.e. one more W
+    // column w[t] = -(sum_j W[t][j] U[0][j]) / norm plus a spike 1/norm at row 0 (added in pass 2).
+    // Any further null directions stay zero columns ("null directions").
+    const int i0 = s_i0;
+    double spike = 0.0;
+    if (i0 >= 0) {  // uniform
+        // centre row 0 exactly as the streaming kernels do (fp32, task order, one divide)
+        float sum = 0.f;
+        for (int t = 0; t < n; ++t) sum += (float)lam[t];
+        const float mean0 = center ? sum / (float)n : 0.f;
+        if (tid < n) xc0[tid] = (double)((float)lam[tid] - mean0);
+        __syncthreads();
+        if (tid < r) {
+            double u = 0.0;
+            for (int t = 0; t < n; ++t) u += xc0[t] * A[t * LDN + tid];
+            u0[tid] = u;  // U[0][tid]
+        }
+        __syncthreads();
+        double norm2 = 1.0;
+        for (int j = 0; j < r; ++j) norm2 -= u0[j] * u0[j];
+        if (norm2 > 0.25) {  // uniform
+            spike = 1.0 / sqrt(norm2);
+            double acc = 0.0;
+            if (tid < n)
+                for (int j = 0; j < r; ++j) acc += A[tid * LDN + j] * u0[j];
+            __syncthreads();
+            if (tid < n) A[tid * LDN + i0] = -spike * acc;
+        }
     }
     __syncthreads();
+    const bool have_col = spike != 0.0;
+    if (tid == 0) {
+        float *aux = Wtab + (size_t)p * (nn + 4) + nn;
+        aux[0] = (float)spike;
+        aux[1] = have_col ? (float)i0 : -1.f;
+        aux[2] = 0.f;
+        aux[3] = 0.f;
+    }
     // W (fp32) and the closed-form coefficients c0[t][i] = u_i^T xc_t of the UNROUNDED basis:
-    //   real direction:      sigma_i * v_i[t]           (U^T Tc = Sigma V^T)
+    //   resolved direction:  sigma_i * v_i[t]           (U^T Tc = Sigma V^T)
     //   completion column:   w^T Gd[:,t] + spike * xc_t[row 0]
     //   zero column:         0
     // pass 2 adds the fp16-rounding correction E^T Tc on top (k_coeff sums both).
-    for (int e = tid; e < n * n; e += EIG_THREADS) {
+    for (int e = tid; e < nn; e += THREADS) {
         const int t = e / n, i = e % n;
-        Wtab[(size_t)p * (n * n + 4) + e] = (float)A[t * LDN + i];
+        Wtab[(size_t)p * (nn + 4) + e] = (float)A[t * LDN + i];
         double cv = 0.0;
         if (i < r) {
-            if (i == s_i0) {
+            if (have_col && i == i0) {
                 for (int t2 = 0; t2 < n; ++t2) cv += A[t2 * LDN + i] * Gd[t2 * n + t];
-                cv += s_spike * xc0[t];
+                cv += spike * xc0[t];
             } else if (sig[i] > 1e-6 * s0 && sig[i] > 0.0) {
                 cv = sig[i] * sgn[i] * V[t * LDN + order[i]];
             }
         }
-        c0_out[(size_t)p * n * n + e] = cv;
+        c0_out[(size_t)p * nn + e] = cv;
     }
 }
 
@@ -327,7 +405,9 @@ __global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restri
 
     const int p = param0 + blockIdx.x, tid = threadIdx.x, n = NT;
     const SvdqParam pd = params[p];
-    reduce_partials(cpart, pd.unit_begin * pack, (pd.unit_begin + pd.unit_count) * pack, n * n, red, C);
+    (void)pack;
+    (void)pd;
+    reduce_partials(cpart, p * SVDQ_RC, (p + 1) * SVDQ_RC, n * n, red, C);  // level-2 partials of k_reduce
 
     const int k = k_in[p], r = r_in[p];
     const int nl = r - k;
@@ -389,16 +469,22 @@ __global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restri
 }
 
 // ------------------------------------------------------------------------------------ launchers
-int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W,
-                    double *c0, uint8_t *small,
-                    int param0, int nparams, hipStream_t st) {
+int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part2, float *W,
+                    double *c0, uint8_t *small, int param0, int nparams, hipStream_t st) {
     const svdq_small_layout &L = pl->small;
-    hipLaunchKernelGGL(k_eig, dim3(nparams), dim3(EIG_THREADS), 0, st, pl->d_params,
-                       reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks,
-                       pl->pack, pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part, W, c0, param0,
-                       reinterpret_cast<float *>(small + L.sigma_off), reinterpret_cast<int32_t *>(small + L.k_off),
-                       reinterpret_cast<int32_t *>(small + L.r_off), reinterpret_cast<float *>(small + L.energy_off),
-                       reinterpret_cast<int64_t *>(small + L.rows_off));
+    auto pp = reinterpret_cast<const float *const *>(ptrs);
+    float *sg = reinterpret_cast<float *>(small + L.sigma_off);
+    int32_t *kk = reinterpret_cast<int32_t *>(small + L.k_off), *rr = reinterpret_cast<int32_t *>(small + L.r_off);
+    float *en = reinterpret_cast<float *>(small + L.energy_off);
+    int64_t *ro = reinterpret_cast<int64_t *>(small + L.rows_off);
+    if (pl->n_tasks <= 8)
+        hipLaunchKernelGGL(k_eig<64>, dim3(nparams), dim3(64), 0, st, pl->d_params, pp, rows_dev, pl->n_tasks,
+                           pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part2, W, c0, param0, sg,
+                           kk, rr, en, ro);
+    else
+        hipLaunchKernelGGL(k_eig<256>, dim3(nparams), dim3(256), 0, st, pl->d_params, pp, rows_dev, pl->n_tasks,
+                           pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part2, W, c0, param0, sg,
+                           kk, rr, en, ro);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 

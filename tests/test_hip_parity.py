@@ -352,6 +352,49 @@ def test_batch_of_ragged_parameters_matches_single_runs(sq, orc):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
+def test_pipelined_schedule_and_ranges_bit_identical(sq, orc):
+    """svdq_compress with the group pipeline (gram / eig / basis_project on separate streams with
+    back-pressure) and the *_range entry points produce exactly the artifacts of the four plain
+    launches."""
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    sizes = [300000, 768, 70001, 1024 * 96, 5000, 262144]
+    N = 8
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 90 + i)] for i, D in enumerate(sizes)]
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=True, low_bits=4, rtvq_stages=2, device=dev,
+              unit_rows=1024)
+    ref = CompressPlan(sizes, N, **kw)
+    tab = ref.pointer_table(vecs)
+    ref.run(tab)
+    torch.cuda.synchronize()
+    # (a) pipelined schedule inside svdq_compress: groups of >= 4 MB, lag 2
+    pip = CompressPlan(sizes, N, flags=(4 << 8) | (2 << 4), **kw)
+    tab2 = pip.pointer_table(vecs)
+    pip.run(tab2)
+    torch.cuda.synchronize()
+    sm = ref.fetch_small()
+
+    def same_artifacts(other):
+        assert torch.equal(other.small, ref.small)
+        for p, D in enumerate(sizes):     # the packed buffers have uninitialised alignment gaps: compare views
+            a = ref.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), D)
+            b = other.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), D)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+    same_artifacts(pip)
+    # (b) stage-by-stage over two parameter ranges on the current stream
+    rng = CompressPlan(sizes, N, **kw)
+    tab3 = rng.pointer_table(vecs)
+    st = torch.cuda.current_stream()
+    for p0, n in ((0, 2), (2, 4)):
+        rng.gram_range(tab3, p0, n, st)
+        rng.eig_range(tab3, p0, n, st)
+        rng.bp_range(tab3, p0, n, st)
+    rng.coeff_range(0, len(sizes), st)
+    torch.cuda.synchronize()
+    same_artifacts(rng)
+
+
 # ------------------------------------------------------------------------------- masks
 def test_masks_vs_reference_vectors(sq):
     g = load_golden("masks.npz")

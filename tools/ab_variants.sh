@@ -1,6 +1,9 @@
 #!/bin/bash
-for mb in 0 64 100 200 400; do for ur in 1024 2048 4096; do
-  timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu --unit-rows $ur --pipeline-mb $mb 2>/dev/null | python -c "
+timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read()); print('pipeline_mb $mb unit_rows $ur groups', d['config']['pipeline_groups'], 'ms', d['ms_per_step'], 'frac', d['path_roofline_frac'])"
-done; done
+d=json.loads(sys.stdin.read()); print('baseline ms', d['ms_per_step'], d['kernels_ms'], 'frac', d['path_roofline_frac'])"
+for cfg in "64 2 2048" "64 3 2048" "64 4 2048" "64 3 4096" "64 3 1024" "128 3 2048" "256 3 2048"; do set -- $cfg
+  timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu --unit-rows $3 --pipeline-mb $1 --pipeline-lag $2 --pipeline-in-c 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('C-pipeline mb $1 lag $2 unit_rows $3 ms', d['ms_per_step'], 'frac', d['path_roofline_frac'])"
+done
