@@ -35,6 +35,12 @@
 #ifndef SVDQ_UNROLL_GRAM
 #define SVDQ_UNROLL_GRAM 8
 #endif
+#ifndef SVDQ_NT_LOADS
+#define SVDQ_NT_LOADS 0
+#endif
+#ifndef SVDQ_NT_STORES
+#define SVDQ_NT_STORES 0
+#endif
 #ifndef SVDQ_PREFETCH2
 #define SVDQ_PREFETCH2 0  // 1: two register sets, loads two blocks ahead (measured: no gain, fewer waves)
 #endif
@@ -65,7 +71,13 @@ __device__ __forceinline__ void load_block(f32x4 (&v)[NTP], gfloat *(&bp)[NTP], 
     const int64_t r = rb + 4 * lane;
     if (rb + SVDQ_BLK_ROWS <= D) {
 #pragma unroll
-        for (int t = 0; t < NTP; ++t) v[t] = *reinterpret_cast<gf32x4 *>(bp[t] + r);
+        for (int t = 0; t < NTP; ++t) {
+#if SVDQ_NT_LOADS
+            v[t] = __builtin_nontemporal_load(reinterpret_cast<gf32x4 *>(bp[t] + r));
+#else
+            v[t] = *reinterpret_cast<gf32x4 *>(bp[t] + r);
+#endif
+        }
     } else {
 #pragma unroll
         for (int t = 0; t < NTP; ++t) {
@@ -236,7 +248,13 @@ __device__ __forceinline__ void copy_out(const void *lds_src, uint8_t *gdst, int
     const int nvec = nbytes >> 4;
     const f32x4 *s4 = reinterpret_cast<const f32x4 *>(lds_src);
     f32x4 *d4 = reinterpret_cast<f32x4 *>(gdst);
-    for (int i = lane; i < nvec; i += 64) d4[i] = s4[i];
+    for (int i = lane; i < nvec; i += 64) {
+#if SVDQ_NT_STORES
+        __builtin_nontemporal_store(s4[i], &d4[i]);
+#else
+        d4[i] = s4[i];
+#endif
+    }
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(lds_src);
     for (int b = (nvec << 4) + 2 * lane; b < nbytes; b += 128)
         *reinterpret_cast<uint16_t *>(gdst + b) = *reinterpret_cast<const uint16_t *>(sb + b);
