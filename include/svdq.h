@@ -191,6 +191,18 @@ int svdq_mask_compact(const void *src_ptrs_dev, const void *dst_ptrs_dev, int32_
                       const uint8_t *mask_dev, int32_t invert, int64_t numel, int64_t *count_dev,
                       void *work_dev, void *stream);
 
+/* ---- merge consumers (the parity reconstruction of R14)
+ *      svdq_reconstruct: reconstruct_from_coefficients (merge.py:144-194):
+ *        out[d] = ((sum_i U_high[d][i] c[i] + sum_j U_low[d][j] c[k+j]) + mean[d]) * scale
+ *        coef_dev: float [k+nl] on the device; mean_dev may be NULL; scale = noise_shrink or 1.
+ *      svdq_mask_expand: reconstruct_from_masked (mask_loader.py:712-763): out = 0; out[mask] = signal;
+ *        out[~mask] = noise (noise_dev may be NULL).  work_dev: svdq_mask_work_bytes(numel) bytes. */
+int svdq_reconstruct(const void *u_high_dev, const void *u_low_dev, int32_t u_fp16, int64_t rows, int32_t k,
+                     int32_t nl, const float *coef_dev, const float *mean_dev, float scale, float *out_dev,
+                     void *stream);
+int svdq_mask_expand(const float *signal_dev, const float *noise_dev, const uint8_t *mask_dev, int64_t numel,
+                     float *out_dev, void *work_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,8 @@ from .compress import (project_to_basis, compress_single_task, compress_masked_r
                        compress_all_parameters)
 from .mask_loader import (combine_masks, compute_union_mask, compute_intersection_mask, compute_majority_mask,
                           apply_mask_to_tensor, get_unmasked_portion, reconstruct_from_masked)
-from .merge import dequantize_and_average, reconstruct_from_coefficients
+from .merge import (dequantize_and_average, reconstruct_from_coefficients, merge_parameter, merge_all_parameters,
+                    apply_merged_deltas)
 from .driver import build_bases, run_basis_and_compress
 from .pipeline import CompressPlan, compress_batch
 

@@ -507,3 +507,108 @@ extern "C" int svdq_project(const void *u_high, const void *u_low, int32_t u_fp1
     hipLaunchKernelGGL(k_project_finish, dim3(1), dim3(64), 0, st, part, grid, k + nl, c_out);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
+
+// ------------------------------------------------------------------------------------ merge consumers
+// reconstruct_from_coefficients (merge.py:144-194): out = ((U_high c_high + U_low c_low) + mean) * scale.
+// HBM-bound: reads the fp16 (or fp32) basis once (e*(k+nl) B/row) + mean, writes 4 B/row.
+// Thread per row; adjacent threads read adjacent rows of the row-major [D,k] / [D,nl] arrays.
+template <typename T>
+__global__ __launch_bounds__(ELT_THREADS) void k_reconstruct(const T *__restrict__ uh, const T *__restrict__ ul,
+                                                             int64_t rows, int k, int nl,
+                                                             const float *__restrict__ coef,
+                                                             const float *__restrict__ mean, float scale,
+                                                             float *__restrict__ out) {
+    __shared__ float c[32];
+    if (threadIdx.x < k + nl) c[threadIdx.x] = coef[threadIdx.x];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * ELT_THREADS;
+    for (int64_t d = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x; d < rows; d += stride) {
+        float hi = 0.f, lo = 0.f;
+        for (int i = 0; i < k; ++i) hi = fmaf(u_load(uh, d * k + i), c[i], hi);
+        for (int j = 0; j < nl; ++j) lo = fmaf(u_load(ul, d * nl + j), c[k + j], lo);
+        float v = __fadd_rn(hi, lo);
+        if (mean) v = __fadd_rn(v, mean[d]);
+        out[d] = __fmul_rn(v, scale);
+    }
+}
+
+extern "C" int svdq_reconstruct(const void *u_high, const void *u_low, int32_t u_fp16, int64_t rows, int32_t k,
+                                int32_t nl, const float *coef, const float *mean, float scale, float *out,
+                                void *stream) {
+    if (rows < 1 || k < 0 || nl < 0 || k + nl > 32 || !out || (k + nl > 0 && !coef) || (k > 0 && !u_high) ||
+        (nl > 0 && !u_low)) {
+        svdq_set_error("svdq_reconstruct: bad argument (k + nl <= 32)");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = project_grid(rows);
+    if (u_fp16)
+        hipLaunchKernelGGL((k_reconstruct<__half>), dim3(grid), dim3(ELT_THREADS), 0, st,
+                           reinterpret_cast<const __half *>(u_high), reinterpret_cast<const __half *>(u_low), rows, k,
+                           nl, coef, mean, scale, out);
+    else
+        hipLaunchKernelGGL((k_reconstruct<float>), dim3(grid), dim3(ELT_THREADS), 0, st,
+                           reinterpret_cast<const float *>(u_high), reinterpret_cast<const float *>(u_low), rows, k, nl,
+                           coef, mean, scale, out);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+// reconstruct_from_masked (mask_loader.py:712-763): out = zeros; out[mask] = signal; out[~mask] = noise.
+// Inverse of the compaction: same tile counts + scan, then a gather by rank.
+__global__ __launch_bounds__(ELT_THREADS) void k_mask_expand(const float *__restrict__ sig,
+                                                             const float *__restrict__ noise,
+                                                             const uint8_t *__restrict__ mask, int64_t numel,
+                                                             const unsigned long long *__restrict__ tile_offsets,
+                                                             float *__restrict__ out) {
+    const int64_t base = (int64_t)blockIdx.x * MASK_TILE + (int64_t)threadIdx.x * 8;
+    unsigned sel = 0, cnt = 0, n = 0;
+    for (int e = 0; e < 8; ++e)
+        if (base + e < numel) {
+            ++n;
+            if (mask[base + e] != 0) {
+                sel |= 1u << e;
+                ++cnt;
+            }
+        }
+    __shared__ unsigned s[ELT_THREADS];
+    s[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 1; off < ELT_THREADS; off <<= 1) {
+        unsigned add = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (!n) return;
+    const unsigned long long t0 = tile_offsets[blockIdx.x] + (s[threadIdx.x] - cnt);  // rank among True
+    const unsigned long long f0 = (unsigned long long)base - t0;                       // rank among False
+    unsigned jt = 0, jf = 0;
+    for (unsigned e = 0; e < n; ++e) {
+        float v;
+        if (sel & (1u << e))
+            v = sig[t0 + jt++];
+        else
+            v = noise ? noise[f0 + jf++] : 0.f;
+        out[base + e] = v;
+    }
+}
+
+extern "C" int svdq_mask_expand(const float *signal, const float *noise, const uint8_t *mask, int64_t numel,
+                                float *out, void *work, void *stream) {
+    if (!signal || !mask || !out || !work || numel < 1) {
+        svdq_set_error("svdq_mask_expand: bad argument");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int ntiles = (int)((numel + MASK_TILE - 1) / MASK_TILE);
+    uint8_t *wb = reinterpret_cast<uint8_t *>(work);
+    unsigned *tile_counts = reinterpret_cast<unsigned *>(wb);
+    unsigned long long *tile_offsets = reinterpret_cast<unsigned long long *>(wb + svdq_align_up((int64_t)ntiles * 4, 256));
+    long long *total = reinterpret_cast<long long *>(wb + svdq_align_up((int64_t)ntiles * 4, 256) +
+                                                     svdq_align_up((int64_t)ntiles * 8, 256));
+    hipLaunchKernelGGL(k_mask_count, dim3(ntiles), dim3(ELT_THREADS), 0, st, mask, 0, numel, tile_counts);
+    hipLaunchKernelGGL(k_mask_scan, dim3(1), dim3(1024), 0, st, tile_counts, ntiles, tile_offsets, total);
+    hipLaunchKernelGGL(k_mask_expand, dim3(ntiles), dim3(ELT_THREADS), 0, st, signal, noise, mask, numel, tile_offsets,
+                       out);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}

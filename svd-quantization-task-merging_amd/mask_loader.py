@@ -131,11 +131,26 @@ def _select(tensor: torch.Tensor, mask: torch.Tensor, invert: bool) -> torch.Ten
 
 def reconstruct_from_masked(masked_values: torch.Tensor, unmasked_values: Optional[torch.Tensor], mask: torch.Tensor,
                             original_shape: torch.Size) -> torch.Tensor:
-    """Reference mask_loader.py:712-763.  Parity consumer, not on the timed path:
-    implemented with device indexing; the merge path is a later row of SURVEY section 8(f)."""
-    flat_mask = mask.flatten().to(masked_values.device)
-    out = torch.zeros(flat_mask.numel(), dtype=masked_values.dtype, device=masked_values.device)
-    out[flat_mask] = masked_values
-    if unmasked_values is not None:
-        out[~flat_mask] = unmasked_values.to(masked_values.device)
-    return out.view(original_shape)
+    """Reference mask_loader.py:712-763: zeros; result[mask] = masked; result[~mask] = unmasked
+    (svdq_mask_expand: the inverse of the compaction, same tile scan)."""
+    lib = nat.lib()
+    out_dev = masked_values.device
+    dev = resolve_device(out_dev if masked_values.is_cuda else "cuda")
+    numel = mask.numel()
+    if numel == 0:
+        return torch.zeros(original_shape, dtype=masked_values.dtype, device=out_dev)
+    if masked_values.dtype != torch.float32:
+        res = reconstruct_from_masked(masked_values.float(), None if unmasked_values is None else
+                                      unmasked_values.float(), mask, original_shape)
+        return res.to(masked_values.dtype)
+    mb = _as_mask_bytes(mask, dev)
+    # one spare element so that an all-False / all-True mask never hands the kernel an empty buffer
+    sig = torch.cat([prepare_vector(masked_values, dev), torch.zeros(1, device=dev)])
+    noi = None if unmasked_values is None else torch.cat([prepare_vector(unmasked_values, dev),
+                                                          torch.zeros(1, device=dev)])
+    out = torch.empty(numel, dtype=torch.float32, device=dev)
+    work = torch.empty(int(lib.svdq_mask_work_bytes(numel)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(lib.svdq_mask_expand(_ptr(sig), _ptr(noi), _ptr(mb), numel, _ptr(out), _ptr(work), _stream_ptr()),
+                  "svdq_mask_expand")
+    return out.view(original_shape).to(out_dev)

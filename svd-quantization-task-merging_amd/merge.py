@@ -1,8 +1,10 @@
 """
-Parity consumers of the artifacts (reference src/svd_hybrid/merge.py:61-194).
-They define the reconstruction that "recon MSE vs ref" is measured on.  Not on the timed path:
-device tensor ops, same arithmetic order as the reference.  The full merge (weights, clusters,
-apply_merged_deltas) is a later row of SURVEY.md section 8(f).
+Coefficient-space merge on the GPU with the reference's callables (SURVEY.md section 8 f1;
+reference src/svd_hybrid/merge.py:61-552).  The heavy step -- U c + mean over every row of a
+parameter -- is `svdq_reconstruct` (HBM-bound: reads the fp16 basis once, writes fp32); the masked
+scatter is `svdq_mask_expand`.  Averaging N x N scalars per parameter is host-sized work on small
+device tensors.  Weighting / clustering (weighting.py, clustering.py) stay out of scope: callers pass
+the ``weights`` dict.
 """
 from __future__ import annotations
 
@@ -10,6 +12,8 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
+from . import _native as nat
+from .pipeline import prepare_vector, resolve_device, _ptr, _stream_ptr
 from .rtvq import RTVQQuantizer
 
 
@@ -37,10 +41,88 @@ def dequantize_and_average(compressed_coeffs: Dict[str, Dict], weights: Dict[str
 def reconstruct_from_coefficients(avg_c_high: torch.Tensor, avg_c_low: torch.Tensor, U_high: torch.Tensor,
                                   U_low: torch.Tensor, device: str = "cpu", mean: Optional[torch.Tensor] = None
                                   ) -> torch.Tensor:
-    """Reference merge.py:144-194: U_high c_high + U_low c_low (+ mean)."""
-    Uh = U_high.to(device).float()
-    Ul = U_low.to(device).float()
-    out = Uh @ avg_c_high.to(device) + Ul @ avg_c_low.to(device)
-    if mean is not None:
-        out = out + mean.squeeze().to(device).float()
+    """Reference merge.py:144-194: U_high c_high + U_low c_low (+ mean); result on the GPU."""
+    return _reconstruct(avg_c_high, avg_c_low, U_high, U_low, mean, 1.0)
+
+
+def _reconstruct(avg_c_high, avg_c_low, U_high, U_low, mean, scale: float) -> torch.Tensor:
+    """``scale`` folds the ``* noise_shrink`` of merge.py:270 into the same streaming pass."""
+    lib = nat.lib()
+    dev = resolve_device(U_high.device if U_high.is_cuda else "cuda")
+    D = U_high.shape[0] if U_high.dim() == 2 else U_low.shape[0]
+    k = U_high.shape[1] if U_high.dim() == 2 else 0
+    nl = U_low.shape[1] if U_low.dim() == 2 else 0
+    if k + nl > 32:
+        raise ValueError("at most 32 basis columns (tasks) are supported")
+    fp16 = (U_high.dtype == torch.float16) if k else (U_low.dtype == torch.float16)
+    dt = torch.float16 if fp16 else torch.float32
+    uh = U_high.to(device=dev, dtype=dt).contiguous() if k else None
+    ul = U_low.to(device=dev, dtype=dt).contiguous() if nl else None
+    coef = torch.cat([avg_c_high.to(dev).float().reshape(-1), avg_c_low.to(dev).float().reshape(-1)]).contiguous()
+    if coef.numel() != k + nl:
+        raise ValueError(f"Shape mismatch: {coef.numel()} coefficients for {k + nl} basis columns")
+    m = prepare_vector(mean.squeeze() if mean.dim() > 1 else mean, dev) if mean is not None else None
+    out = torch.empty(D, dtype=torch.float32, device=dev)
+    if D == 0:
+        return out
+    with torch.cuda.device(dev):
+        nat.check(lib.svdq_reconstruct(_ptr(uh), _ptr(ul), int(fp16), D, k, nl, _ptr(coef), _ptr(m), float(scale),
+                                       _ptr(out), _stream_ptr()), "svdq_reconstruct")
+    return out
+
+
+def merge_parameter(param_name: str, compressed_params: Dict[str, Dict], basis: Dict, weights: Dict[str, float],
+                    quantizer: RTVQQuantizer, original_shape: torch.Size, mask: Optional[torch.Tensor] = None,
+                    include_noise: bool = False, noise_shrink: float = 1.0, device: str = "cpu") -> torch.Tensor:
+    """Reference merge.py:197-301."""
+    from .mask_loader import reconstruct_from_masked
+    dev = resolve_device(device)
+    merged_masked = merged_unmasked = None
+    bm = basis.get("masked")
+    if bm is not None:
+        ch, cl = dequantize_and_average(compressed_params, weights, quantizer, region="masked", device=dev)
+        if ch is not None:
+            merged_masked = reconstruct_from_coefficients(ch, cl, bm["U_high"], bm["U_low"], device=dev,
+                                                          mean=bm.get("mean"))
+    if include_noise:
+        bu = basis.get("noise")
+        if bu is not None:
+            ch, cl = dequantize_and_average(compressed_params, weights, quantizer, region="unmasked", device=dev)
+            if ch is not None:
+                merged_unmasked = _reconstruct(ch, cl, bu["U_high"], bu["U_low"], bu.get("mean"), noise_shrink)
+    if mask is not None and merged_masked is not None:
+        return reconstruct_from_masked(merged_masked, merged_unmasked, mask, original_shape)
+    if merged_masked is not None:
+        return merged_masked.view(original_shape)
+    return torch.zeros(original_shape, device=dev)
+
+
+def merge_all_parameters(compressed_all: Dict[str, Dict[str, Dict]], bases: Dict[str, Dict],
+                         masks: Dict[str, torch.Tensor], weights: Dict[str, float],
+                         original_shapes: Dict[str, torch.Size], config, device: str = "cpu",
+                         verbose: bool = True) -> Dict[str, torch.Tensor]:
+    """Reference merge.py:304-426: parameters in sorted order, one quantizer for the run."""
+    quantizer = RTVQQuantizer(num_bits=config.svd_low_bits, num_stages=config.svd_rtvq_stages)
+    merged = {}
+    for name in sorted(compressed_all.keys()):
+        merged[name] = merge_parameter(name, compressed_all[name], bases[name], weights, quantizer,
+                                       original_shapes[name], mask=masks.get(name),
+                                       include_noise=config.svd_include_noise, noise_shrink=config.svd_noise_shrink,
+                                       device=device)
+    if verbose:
+        print(f"   merged {len(merged)} parameters")
+    return merged
+
+
+def apply_merged_deltas(base_state_dict: Dict[str, torch.Tensor], merged_deltas: Dict[str, torch.Tensor],
+                        device: str = "cpu", verbose: bool = True) -> Dict[str, torch.Tensor]:
+    """Reference merge.py:429-552: merged[param] = base[param] + delta[param]; others are cloned."""
+    out = {}
+    for name, base in base_state_dict.items():
+        if name in merged_deltas:
+            out[name] = base + merged_deltas[name].to(base.device)
+        else:
+            out[name] = base.clone()
+    if verbose:
+        print(f"   applied {sum(n in merged_deltas for n in base_state_dict)} merged deltas")
     return out

@@ -22,6 +22,7 @@ Fixture families (all .npz, loadable with allow_pickle=False):
                   reconstruct_from_masked / construct_masked_basis(include_noise)
   pipeline.npz    cli.py Step 4 + Step 5 loop bodies over 3 layers x 4 tasks
                   (construct_masked_basis + compress_all_parameters), dict layout + numbers
+  merge.npz       merge_all_parameters + apply_merged_deltas (merge.py:304-552), 6 tasks, weighted
 """
 import json
 import os
@@ -368,6 +369,69 @@ def gen_pipeline():
     save("pipeline.npz", **out)
 
 
+# ------------------------------------------------------------------------------- merge
+def gen_merge():
+    """merge_all_parameters + apply_merged_deltas (merge.py:304-552) over a toy model whose c_low always
+    has >= 3 elements (6 tasks, max_rank 2), non-uniform weights, one masked parameter with a noise region."""
+    shapes = {"a.weight": (96, 64), "a.bias": (96,), "b.weight": (80, 40)}
+    tasks = ["T0", "T1", "T2", "T3", "T4", "T5"]
+    cfg = types.SimpleNamespace(svd_low_bits=4, svd_rtvq_stages=2, svd_include_noise=True, svd_min_mask_size=10,
+                                svd_energy_threshold=0.9, svd_max_rank=2, svd_center=True, svd_fp16=True,
+                                svd_noise_shrink=0.5)
+    weights = {"T0": 0.3, "T1": 0.1, "T2": 0.2, "T3": 0.15, "T4": 0.05, "T5": 0.2}
+    g = torch.Generator().manual_seed(8)
+    task_vectors = {t: {} for t in tasks}
+    out = {}
+    masks = {}
+    for pi, (pname, shp) in enumerate(sorted(shapes.items())):
+        ds = synthetic_deltas(int(np.prod(shp)), len(tasks), 300 + pi)
+        for t, d in zip(tasks, ds):
+            task_vectors[t][pname] = d.view(shp)
+        out[f"in__{pname}"] = torch.stack(ds).numpy()
+    masks["b.weight"] = torch.rand(shapes["b.weight"], generator=g) > 0.4
+    out["mask__b.weight"] = masks["b.weight"].numpy()
+    bases = {}
+    for pname in sorted(shapes):
+        mask = masks.get(pname)
+        md, ud = [], []
+        for t in tasks:
+            delta = task_vectors[t][pname]
+            if mask is not None and mask.shape == delta.shape:
+                md.append(ref_masks.apply_mask_to_tensor(delta, mask))
+                ud.append(ref_masks.get_unmasked_portion(delta, mask))
+            else:
+                md.append(delta.flatten())
+        basis = ref_basis.construct_masked_basis(md, ud if ud else None, energy_threshold=cfg.svd_energy_threshold,
+                                                 max_rank=cfg.svd_max_rank, center=cfg.svd_center, device="cpu",
+                                                 include_noise=cfg.svd_include_noise)
+        for region in ("masked", "noise"):
+            if basis.get(region) is not None:
+                basis[region]["U_high"] = basis[region]["U_high"].half()
+                basis[region]["U_low"] = basis[region]["U_low"].half()
+                assert basis[region]["N"] - basis[region]["k"] >= 3
+        bases[pname] = basis
+    compressed = ref_compress.compress_all_parameters(task_vectors, masks, bases, cfg, device="cpu")
+    original_shapes = {n: torch.Size(s) for n, s in shapes.items()}
+    merged = ref_merge.merge_all_parameters(compressed, bases, masks, weights, original_shapes, cfg, device="cpu",
+                                            verbose=False)
+    base_sd = {n: torch.randn(s, generator=g) for n, s in shapes.items()}
+    base_sd["extra.buffer"] = torch.arange(5, dtype=torch.float32)
+    final = ref_merge.apply_merged_deltas(base_sd, merged, device="cpu", verbose=False)
+    for n in shapes:
+        assert torch.isfinite(merged[n]).all()
+        out[f"merged__{n}"] = merged[n].numpy()
+        out[f"base__{n}"] = base_sd[n].numpy()
+        out[f"final__{n}"] = final[n].numpy()
+    # weighted average of the exact task deltas: what the merge approximates
+    for n in shapes:
+        exact = sum(weights[t] * task_vectors[t][n] for t in tasks)
+        out[f"exact__{n}"] = exact.numpy()
+    out["tasks"] = np.array(tasks)
+    out["weights"] = np.array([weights[t] for t in tasks], dtype=np.float64)
+    out["params"] = np.array(sorted(shapes))
+    save("merge.npz", **out)
+
+
 # ------------------------------------------------------------------------------- rank KATs
 def gen_rank():
     out = {}
@@ -400,3 +464,4 @@ if __name__ == "__main__":
     gen_config1()
     gen_masks()
     gen_pipeline()
+    gen_merge()

@@ -1,0 +1,89 @@
+"""
+GPU tests of the merge consumers: svdq_reconstruct / svdq_mask_expand and the
+reference-shaped merge_parameter / merge_all_parameters / apply_merged_deltas, against vectors produced
+by the reference (tests/golden/merge.npz) and against the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sq():
+    import svdq_amd
+    return svdq_amd
+
+
+def test_reconstruct_kernel_vs_oracle(sq):
+    from oracle import svd_hybrid_oracle as orc
+    g = torch.Generator().manual_seed(1)
+    for D, k, nl, fp16, with_mean in ((100, 2, 2, False, True), (70001, 3, 5, True, True), (4096, 8, 0, True, False),
+                                      (1000003, 1, 7, True, True), (513, 0, 4, False, True)):
+        Q, _ = torch.linalg.qr(torch.randn(D, max(k + nl, 1), generator=g))
+        Uh, Ul = Q[:, :k].contiguous(), Q[:, k:k + nl].contiguous()
+        if fp16:
+            Uh, Ul = Uh.half(), Ul.half()
+        ch, cl = torch.randn(k, generator=g), torch.randn(nl, generator=g)
+        mean = torch.randn(D, 1, generator=g) if with_mean else None
+        want = orc.reconstruct(ch, cl, Uh, Ul, mean).numpy()
+        got = sq.reconstruct_from_coefficients(ch, cl, Uh.cuda(), Ul.cuda(), "cuda", mean=mean)
+        assert got.device.type == "cuda" and got.shape == (D,)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_mask_expand_vs_torch(sq):
+    g = torch.Generator().manual_seed(2)
+    for shape, dens in (((40, 50), 0.6), ((2047,), 0.5), ((2049, 3), 0.03), ((1_000_003,), 0.94), ((4096,), 0.0),
+                        ((4096,), 1.0), ((1,), 1.0)):
+        mask = torch.rand(shape, generator=g) < dens
+        full = torch.randn(shape, generator=g)
+        sig, noi = full.flatten()[mask.flatten()], full.flatten()[~mask.flatten()]
+        back = sq.reconstruct_from_masked(sig.cuda(), noi.cuda(), mask.cuda(), full.shape)
+        assert torch.equal(back.cpu(), full)
+        only = sq.reconstruct_from_masked(sig.cuda(), None, mask.cuda(), full.shape).cpu()
+        want = torch.zeros_like(full)
+        want[mask] = sig
+        assert torch.equal(only, want)
+
+
+def test_merge_vs_reference_vectors(sq):
+    g = load_golden("merge.npz")
+    tasks = [str(t) for t in g["tasks"]]
+    params = [str(p) for p in g["params"]]
+    weights = {t: float(w) for t, w in zip(tasks, g["weights"])}
+    cfg = sq.SVDHybridConfig(svd_energy_threshold=0.9, svd_max_rank=2, svd_center=True, svd_fp16=True, svd_low_bits=4,
+                             svd_rtvq_stages=2, svd_include_noise=True, svd_min_mask_size=10, svd_noise_shrink=0.5)
+    tv = {t: {} for t in tasks}
+    masks, shapes = {}, {}
+    for p in params:
+        shape = g[f"merged__{p}"].shape
+        shapes[p] = torch.Size(shape)
+        for i, t in enumerate(tasks):
+            tv[t][p] = torch.from_numpy(g[f"in__{p}"][i]).view(*shape).cuda()
+        if f"mask__{p}" in g:
+            masks[p] = torch.from_numpy(g[f"mask__{p}"]).cuda()
+    bases, comp = sq.run_basis_and_compress(tv, masks, cfg, "cuda")
+    merged = sq.merge_all_parameters(comp, bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
+    assert sorted(merged.keys()) == sorted(params)
+    for p in params:
+        m = merged[p].cpu().numpy()
+        assert m.shape == g[f"merged__{p}"].shape and np.isfinite(m).all()
+        # vs the reference's merged delta: both carry independent quantization noise of the low coefficients
+        assert float(np.mean((m - g[f"merged__{p}"]) ** 2)) <= 1e-6
+        # and it approximates the exact weighted average as well as the reference does
+        ex = g[f"exact__{p}"]
+        err = np.linalg.norm(m - ex) / np.linalg.norm(ex)
+        err_ref = np.linalg.norm(g[f"merged__{p}"] - ex) / np.linalg.norm(ex)
+        assert err <= 1.5 * err_ref + 1e-3, (p, err, err_ref)
+    base = {p: torch.from_numpy(g[f"base__{p}"]).cuda() for p in params}
+    base["extra.buffer"] = torch.arange(5, dtype=torch.float32).cuda()
+    final = sq.apply_merged_deltas(base, merged, device="cuda", verbose=False)
+    assert set(final.keys()) == set(base.keys()) and torch.equal(final["extra.buffer"], base["extra.buffer"])
+    assert final["extra.buffer"].data_ptr() != base["extra.buffer"].data_ptr()
+    for p in params:
+        assert torch.equal(final[p], base[p] + merged[p])
+        assert float(np.mean((final[p].cpu().numpy() - g[f"final__{p}"]) ** 2)) <= 1e-6
