@@ -134,11 +134,20 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        # rehearsal on a box with fewer GPUs than ranks: SVDQ_DIST_BACKEND=gloo lets several ranks share a
+        # card (RCCL refuses duplicate devices); the real run is one rank per GPU over nccl (= RCCL)
+        backend = os.environ.get("SVDQ_DIST_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        local_dev = local_rank % max(ndev, 1)
+        torch.cuda.set_device(local_dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        local_rank = local_dev
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    on_cpu = world > 1 and os.environ.get("SVDQ_DIST_BACKEND", "nccl") != "nccl"   # gloo: collectives on host tensors
 
     import svdq_amd
     from svdq_amd import workloads, shard
@@ -217,7 +226,7 @@ def main():
             events[3].record(); plan.coeff_quantize()
             events[4].record()
         if world > 1:
-            shard.gather_small(plan.small)
+            shard.gather_small(plan.small.cpu() if on_cpu else plan.small)
 
     for _ in range(args.warmup):
         step()
@@ -233,10 +242,11 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = "cpu" if on_cpu else dev
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tot = torch.tensor([float(sum(rows)) * N], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(sum(rows)) * N], dtype=torch.float64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_scalars = float(tot.item())
     else:

@@ -51,6 +51,15 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// One wavefront per workgroup: LDS operations of a wave execute in order, so phases only need the
+// COMPILER kept from moving LDS accesses across the boundary.  __syncthreads() would also emit
+// s_waitcnt vmcnt(0), draining this wave's global stores and prefetched loads once per block.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ f32x4 zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ param
 
     auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
         center_store<NTP>(v, NT, center, X, lane);
-        __syncthreads();
+        wave_sync();
         if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
 
         f32x4 acc[NACC];
@@ -206,7 +215,7 @@ UNROLL_N(SVDQ_UNROLL_GRAM)
         for (int i = 0; i < NACC; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) accd[i][e] += (double)acc[i][e];
-        __syncthreads();
+        wave_sync();
     };
 
     for (int64_t rb = r_begin; rb < r_end; rb += AHEAD * SVDQ_BLK_ROWS) {
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(64) void k_basis_project(
                 if (rr + 2 < D) gmean[rr + 2] = mean.z;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
 
         f32x4 cf[NCB];
@@ -486,7 +495,7 @@ UNROLL_N(SVDQ_UNROLL_BP)
         for (int i = 0; i < NCB; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) caccd[i][e] += (double)cf[i][e];
-        __syncthreads();
+        wave_sync();
 
         // stream the two row-major output tiles of this block out of LDS, 16 B per lane
         const int rows_blk = (int)((D - rb < SVDQ_BLK_ROWS) ? (D - rb) : SVDQ_BLK_ROWS);
@@ -496,7 +505,7 @@ UNROLL_N(SVDQ_UNROLL_BP)
 #else
         if (rows_blk < 0) copy_out(OUTh, gUh, 16, lane);  // diagnostic build: keep OUT live, skip the stores
 #endif
-        __syncthreads();
+        wave_sync();
     };
 
     for (int64_t rb = r_begin; rb < r_end; rb += AHEAD * SVDQ_BLK_ROWS) {
