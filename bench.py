@@ -56,6 +56,9 @@ def parse():
                     help="experimental: group parameters into >= this many MB of input and pipeline "
                          "gram(g+1) | eig(g) on a side stream | basis_project(g) so a group's deltas are still "
                          "in the Infinity Cache for its second pass (0 = four whole-model launches)")
+    ap.add_argument("--masks", choices=("none", "union", "intersection", "majority"), default="none",
+                    help="BASELINE configs[2]: per-task tall masks (rand > 0.7) combined on device, then every "
+                         "parameter compacted under its combined mask before the four stages")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -171,6 +174,16 @@ def main():
                         low_bits=args.bits, rtvq_stages=args.stages, device=dev, unit_rows=args.unit_rows,
                         flags=flags)
     table = plan.pointer_table(views)
+    mset = rows_dev = None
+    if args.masks != "none":
+        from svdq_amd.mask_loader import MaskSet
+        gm = torch.Generator(device=dev).manual_seed(77 + rank)
+        per_task = [[torch.rand(r, device=dev, generator=gm) > 0.7 for _ in range(N)] for r in rows]
+        mset = MaskSet(rows, dev)
+        comb, counts = mset.prepare_combine(per_task, args.masks)
+        dt, _, ct, _ = mset.prepare_compact([c.view(torch.bool) for c in comb], views, want_false=False)
+        table = plan.pointer_table(dt)
+        rows_dev = ct
     torch.cuda.synchronize()
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
@@ -215,6 +228,13 @@ def main():
         plan.coeff_range(0, len(rows), main)
 
     def step(events=None):
+        if mset is not None:
+            mset.run_combine()
+            mset.run_compact()
+            plan.run(table, rows_dev)
+            if world > 1:
+                shard.gather_small(plan.small.cpu() if on_cpu else plan.small)
+            return
         if groups:
             step_pipelined()
         elif events is None or args.pipeline_in_c:
@@ -254,7 +274,7 @@ def main():
 
     # per-kernel HIP-event times (this rank), averaged over the timed steps
     kms = [0.0] * 4
-    if not groups and not args.pipeline_in_c:
+    if not groups and not args.pipeline_in_c and mset is None:
         for s in range(args.steps):
             for i in range(4):
                 kms[i] += ev[s][i].elapsed_time(ev[s][i + 1])
@@ -284,6 +304,8 @@ def main():
                                    f"{args.bits}-bit x {args.stages}-stage RTVQ",
                        "tensors_per_gpu": len(rows), "tasks": N, "mean_rank_k": round(k_mean, 2),
                        "units": int(plan.sizes.n_units), "pipeline_groups": len(groups),
+                       "masks": args.masks, "mask_density": (round(float(sm.rows.sum()) / sumD, 4)
+                                                             if args.masks != "none" else None),
                        "sharding": "none" if world == 1 else (
                            "one model per rank" if args.scaling == "weak" else "LPT over parameter tensors")},
             "roofline": {"bound": "hbm", "kernel": "k_basis_project", "achieved": round(bp_gbs, 1),

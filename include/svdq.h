@@ -191,6 +191,24 @@ int svdq_mask_compact(const void *src_ptrs_dev, const void *dst_ptrs_dev, int32_
                       const uint8_t *mask_dev, int32_t invert, int64_t numel, int64_t *count_dev,
                       void *work_dev, void *stream);
 
+/* ---- the mask operators over a ragged SET of parameters in a handful of launches (the reference runs
+ *      them once per parameter and task: cli.py:324-341, compress.py:140-155).  numel[q] = elements of
+ *      masked parameter q.  Tables are device arrays of device pointers:
+ *        mask_ptrs [Q*n_masks] uint8 per-task masks (combine) / [Q] combined masks (compact)
+ *        out_ptrs  [Q] combined mask outputs;  src/dst [Q*n_src] fp32 buffers (dst sized numel[q])
+ *      counts stay on the device (int64 [Q]): mask.sum() and (~mask).sum(); they feed rows_dev.
+ *      svdq_maskset_compact writes flat[mask] to dst_true and, when dst_false_ptrs != NULL,
+ *      flat[~mask] to dst_false in the same pass.  work_dev: svdq_maskset_work_bytes() bytes. */
+typedef struct svdq_maskset svdq_maskset;
+int     svdq_maskset_create(svdq_maskset **ms, int32_t n_params, const int64_t *numel);
+void    svdq_maskset_destroy(svdq_maskset *ms);
+int64_t svdq_maskset_work_bytes(const svdq_maskset *ms);
+int     svdq_maskset_combine(const svdq_maskset *ms, const void *mask_ptrs_dev, int32_t n_masks, int32_t strategy,
+                             const void *out_ptrs_dev, int64_t *counts_dev, void *stream);
+int     svdq_maskset_compact(const svdq_maskset *ms, const void *mask_ptrs_dev, const void *src_ptrs_dev,
+                             const void *dst_true_ptrs_dev, const void *dst_false_ptrs_dev, int32_t n_src,
+                             int64_t *count_true_dev, int64_t *count_false_dev, void *work_dev, void *stream);
+
 /* ---- merge consumers (the parity reconstruction of R14)
  *      svdq_reconstruct: reconstruct_from_coefficients (merge.py:144-194):
  *        out[d] = ((sum_i U_high[d][i] c[i] + sum_j U_low[d][j] c[k+j]) + mean[d]) * scale

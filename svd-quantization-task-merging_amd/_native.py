@@ -66,6 +66,12 @@ SIGNATURES = {
     "svdq_mask_combine": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_mask_compact": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p,
                                     c_void_p]),
+    "svdq_maskset_create": (c_int32, [POINTER(c_void_p), c_int32, POINTER(c_int64)]),
+    "svdq_maskset_destroy": (None, [c_void_p]),
+    "svdq_maskset_work_bytes": (c_int64, [c_void_p]),
+    "svdq_maskset_combine": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "svdq_maskset_compact": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
     "svdq_project": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
     "svdq_project_work_bytes": (c_int64, [c_int64, c_int32]),

@@ -13,6 +13,7 @@
 
 #include "svdq_common.h"
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #define ELT_THREADS 256
 #define RTVQ_MAX_BLOCKS 2048
@@ -257,30 +258,49 @@ extern "C" int svdq_rtvq_dequantize(const uint8_t *codes, int64_t code_stride, i
 // ------------------------------------------------------------------------------------ masks
 #define MASK_TILE 2048  // elements per block: 256 threads x 8
 
-// mask_loader.py:412-485.  torch.bool storage is one byte per element, 0 or 1.
-__global__ __launch_bounds__(ELT_THREADS) void k_mask_combine(const uint8_t *const *__restrict__ masks, int n_masks,
-                                                              int64_t numel, int strategy, uint8_t *__restrict__ out,
-                                                              unsigned long long *__restrict__ count) {
-    const int64_t base = (int64_t)blockIdx.x * MASK_TILE + (int64_t)threadIdx.x * 8;
+// ---- tile helpers shared by the single-parameter and the batched mask kernels ------------------
+// torch.bool storage is one byte per element holding 0 or 1, so 8 mask bytes can be voted on at once:
+// byte lanes of a 64-bit word accumulate the per-element counts (n_masks <= 32 < 256, no carries).
+__device__ __forceinline__ unsigned long long load_mask8(const uint8_t *p, int lim) {
+    unsigned long long w = 0;
+    if (lim == 8 && (reinterpret_cast<uintptr_t>(p) & 7) == 0) return *reinterpret_cast<const unsigned long long *>(p);
+    for (int e = 0; e < lim; ++e) w |= (unsigned long long)(p[e] != 0) << (8 * e);
+    return w;
+}
+
+__device__ __forceinline__ unsigned long long vote8(unsigned long long acc, int n_masks, int strategy) {
+    unsigned long long out = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int v = (int)((acc >> (8 * e)) & 0xff);
+        int bit;
+        if (strategy == SVDQ_MASK_UNION)
+            bit = v > 0;
+        else if (strategy == SVDQ_MASK_INTERSECTION)
+            bit = v == n_masks;
+        else
+            bit = 2 * v >= n_masks;  // vote_sum >= 0.5 * len(masks), mask_loader.py:483
+        out |= (unsigned long long)bit << (8 * e);
+    }
+    return out;
+}
+
+// one 2048-element tile: combined mask out, number of selected elements returned by thread 0 via *cnt_out
+__device__ void combine_tile(const uint8_t *const *masks, int n_masks, int strategy, int64_t tile, int64_t numel,
+                             uint8_t *out, unsigned *cnt_out) {
+    const int64_t base = tile * MASK_TILE + (int64_t)threadIdx.x * 8;
     unsigned cnt = 0;
     if (base < numel) {
         const int lim = (int)((numel - base) < 8 ? (numel - base) : 8);
-        int votes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int m = 0; m < n_masks; ++m) {
-            const uint8_t *src = masks[m] + base;
-            for (int e = 0; e < lim; ++e) votes[e] += src[e] ? 1 : 0;
+        unsigned long long acc = 0;
+        for (int m = 0; m < n_masks; ++m) acc += load_mask8(masks[m] + base, lim);
+        const unsigned long long res = vote8(acc, n_masks, strategy);
+        if (lim == 8 && (reinterpret_cast<uintptr_t>(out + base) & 7) == 0) {
+            *reinterpret_cast<unsigned long long *>(out + base) = res;
+        } else {
+            for (int e = 0; e < lim; ++e) out[base + e] = (uint8_t)((res >> (8 * e)) & 1);
         }
-        for (int e = 0; e < lim; ++e) {
-            int bit;
-            if (strategy == SVDQ_MASK_UNION)
-                bit = votes[e] > 0;
-            else if (strategy == SVDQ_MASK_INTERSECTION)
-                bit = votes[e] == n_masks;
-            else
-                bit = 2 * votes[e] >= n_masks;  // vote_sum >= 0.5 * len(masks), mask_loader.py:483
-            out[base + e] = (uint8_t)bit;
-            cnt += bit;
-        }
+        cnt = (unsigned)__popcll(lim == 8 ? res : (res & ((1ull << (8 * lim)) - 1)));
     }
     __shared__ unsigned s_cnt[ELT_THREADS];
     s_cnt[threadIdx.x] = cnt;
@@ -289,7 +309,81 @@ __global__ __launch_bounds__(ELT_THREADS) void k_mask_combine(const uint8_t *con
         if (threadIdx.x < off) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && s_cnt[0]) atomicAdd(count, (unsigned long long)s_cnt[0]);
+    if (threadIdx.x == 0) *cnt_out = s_cnt[0];
+}
+
+// one tile of an order-preserving compaction for n_src buffers: every source tile is loaded with
+// 16-B loads, compacted through LDS (selected -> one image, unselected -> a second one when asked)
+// and written out as ONE contiguous, coalesced run per region.
+__device__ void scatter_tile(const uint8_t *mask, int64_t tile, int64_t numel, const float *const *src,
+                             float *const *dst_true, float *const *dst_false, int n_src,
+                             unsigned long long tile_off) {
+    __shared__ unsigned s[ELT_THREADS];
+    __shared__ float lt[MASK_TILE], lf[MASK_TILE];
+    const int tid = threadIdx.x;
+    const int64_t tbase = tile * MASK_TILE;
+    const int64_t base = tbase + (int64_t)tid * 8;
+    const int lim = base < numel ? (int)((numel - base) < 8 ? (numel - base) : 8) : 0;
+    const unsigned long long w = lim ? load_mask8(mask + base, lim) : 0;
+    unsigned sel = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sel |= (unsigned)((w >> (8 * e)) & 1) << e;
+    const unsigned cnt = __popc(sel);
+    s[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < ELT_THREADS; off <<= 1) {
+        unsigned add = tid >= off ? s[tid - off] : 0;
+        __syncthreads();
+        s[tid] += add;
+        __syncthreads();
+    }
+    const unsigned tot_true = s[ELT_THREADS - 1];
+    const int tile_n = (int)((numel - tbase) < MASK_TILE ? (numel - tbase) : MASK_TILE);
+    const unsigned tot_false = (unsigned)tile_n - tot_true;
+    const unsigned pt = s[tid] - cnt;                 // rank of this thread's first selected element
+    const unsigned pf = (unsigned)(tid * 8) - pt;     // ... and of its first unselected one
+    const unsigned long long f_off = (unsigned long long)tbase - tile_off;
+    for (int m = 0; m < n_src; ++m) {
+        const float *sp = src[m] + base;
+        float v[8];
+        if (lim == 8 && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
+            const f32x4 a = reinterpret_cast<const f32x4 *>(sp)[0], b = reinterpret_cast<const f32x4 *>(sp)[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = e < lim ? sp[e] : 0.f;
+        }
+        unsigned jt = pt, jf = pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (e < lim) {
+                if (sel & (1u << e))
+                    lt[jt++] = v[e];
+                else
+                    lf[jf++] = v[e];
+            }
+        }
+        __syncthreads();
+        if (dst_true) {
+            float *dt = dst_true[m] + tile_off;
+            for (unsigned i = tid; i < tot_true; i += ELT_THREADS) dt[i] = lt[i];
+        }
+        if (dst_false) {
+            float *df = dst_false[m] + f_off;
+            for (unsigned i = tid; i < tot_false; i += ELT_THREADS) df[i] = lf[i];
+        }
+        __syncthreads();
+    }
+}
+
+// mask_loader.py:412-485.  torch.bool storage is one byte per element, 0 or 1.
+__global__ __launch_bounds__(ELT_THREADS) void k_mask_combine(const uint8_t *const *__restrict__ masks, int n_masks,
+                                                              int64_t numel, int strategy, uint8_t *__restrict__ out,
+                                                              unsigned long long *__restrict__ count) {
+    __shared__ unsigned cnt;
+    combine_tile(masks, n_masks, strategy, blockIdx.x, numel, out, &cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(count, (unsigned long long)cnt);
 }
 
 __global__ __launch_bounds__(ELT_THREADS) void k_mask_count(const uint8_t *__restrict__ mask, int invert, int64_t numel,
@@ -341,30 +435,14 @@ __global__ __launch_bounds__(ELT_THREADS) void k_mask_scatter(const float *const
                                                               const uint8_t *__restrict__ mask, int invert,
                                                               int64_t numel,
                                                               const unsigned long long *__restrict__ tile_offsets) {
-    const int64_t base = (int64_t)blockIdx.x * MASK_TILE + (int64_t)threadIdx.x * 8;
-    unsigned sel = 0, cnt = 0;
-    for (int e = 0; e < 8; ++e)
-        if (base + e < numel && ((mask[base + e] != 0) != (invert != 0))) {
-            sel |= 1u << e;
-            ++cnt;
-        }
-    __shared__ unsigned s[ELT_THREADS];
-    s[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int off = 1; off < ELT_THREADS; off <<= 1) {
-        unsigned add = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-        __syncthreads();
-        s[threadIdx.x] += add;
-        __syncthreads();
-    }
-    if (!cnt) return;
-    const unsigned long long pos0 = tile_offsets[blockIdx.x] + (s[threadIdx.x] - cnt);
-    for (int m = 0; m < n_src; ++m) {
-        const float *sp = src[m] + base;
-        float *dp = dst[m] + pos0;
-        unsigned j = 0;
-        for (int e = 0; e < 8; ++e)
-            if (sel & (1u << e)) dp[j++] = sp[e];
+    // tile_offsets were scanned over the SELECTED count (mask != invert); scatter_tile wants the offset of the
+    // True elements, so for invert the roles of its two outputs are swapped
+    const unsigned long long off = tile_offsets[blockIdx.x];
+    if (!invert) {
+        scatter_tile(mask, blockIdx.x, numel, src, dst, nullptr, n_src, off);
+    } else {
+        const unsigned long long true_off = (unsigned long long)blockIdx.x * MASK_TILE - off;
+        scatter_tile(mask, blockIdx.x, numel, src, nullptr, dst, n_src, true_off);
     }
 }
 
@@ -610,5 +688,210 @@ extern "C" int svdq_mask_expand(const float *signal, const float *noise, const u
     hipLaunchKernelGGL(k_mask_scan, dim3(1), dim3(1024), 0, st, tile_counts, ntiles, tile_offsets, total);
     hipLaunchKernelGGL(k_mask_expand, dim3(ntiles), dim3(ELT_THREADS), 0, st, signal, noise, mask, numel, tile_offsets,
                        out);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+
+// ------------------------------------------------------------------------------------ batched masks
+// The same operators over a ragged SET of parameters in a handful of launches (cli.py runs them once
+// per parameter and task): a tile table maps every 2048-element tile to (parameter,
+// tile-in-parameter); per-parameter counts stay on the device and feed rows_dev of the plan.
+struct svdq_maskset {
+    int32_t n_params, n_tiles;
+    int64_t *h_numel;
+    int32_t *h_tile_begin;
+    int64_t *d_numel;        // [Q]
+    int32_t *d_tile_begin;   // [Q+1]
+    int32_t *d_tile_param;   // [n_tiles]
+};
+
+extern "C" int svdq_maskset_create(svdq_maskset **out, int32_t n_params, const int64_t *numel) {
+    if (!out || !numel || n_params < 1) {
+        svdq_set_error("svdq_maskset_create: bad argument");
+        return SVDQ_EINVAL;
+    }
+    svdq_maskset *ms = (svdq_maskset *)calloc(1, sizeof(svdq_maskset));
+    ms->n_params = n_params;
+    ms->h_numel = (int64_t *)calloc(n_params, sizeof(int64_t));
+    ms->h_tile_begin = (int32_t *)calloc(n_params + 1, sizeof(int32_t));
+    int64_t tiles = 0;
+    for (int q = 0; q < n_params; ++q) {
+        if (numel[q] < 1) {
+            svdq_set_error("svdq_maskset_create: parameter %d has %lld elements", q, (long long)numel[q]);
+            free(ms->h_numel);
+            free(ms->h_tile_begin);
+            free(ms);
+            return SVDQ_EINVAL;
+        }
+        ms->h_numel[q] = numel[q];
+        ms->h_tile_begin[q] = (int32_t)tiles;
+        tiles += (numel[q] + MASK_TILE - 1) / MASK_TILE;
+    }
+    ms->h_tile_begin[n_params] = (int32_t)tiles;
+    ms->n_tiles = (int32_t)tiles;
+    int32_t *tp = (int32_t *)malloc(sizeof(int32_t) * tiles);
+    for (int q = 0; q < n_params; ++q)
+        for (int t = ms->h_tile_begin[q]; t < ms->h_tile_begin[q + 1]; ++t) tp[t] = q;
+    hipError_t e = hipMalloc((void **)&ms->d_numel, sizeof(int64_t) * n_params);
+    if (e == hipSuccess) e = hipMalloc((void **)&ms->d_tile_begin, sizeof(int32_t) * (n_params + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&ms->d_tile_param, sizeof(int32_t) * tiles);
+    if (e == hipSuccess) e = hipMemcpy(ms->d_numel, ms->h_numel, sizeof(int64_t) * n_params, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(ms->d_tile_begin, ms->h_tile_begin, sizeof(int32_t) * (n_params + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ms->d_tile_param, tp, sizeof(int32_t) * tiles, hipMemcpyHostToDevice);
+    free(tp);
+    if (e != hipSuccess) {
+        svdq_set_error("svdq_maskset_create: %s", hipGetErrorString(e));
+        svdq_maskset_destroy(ms);
+        return SVDQ_EHIP;
+    }
+    *out = ms;
+    return SVDQ_OK;
+}
+
+extern "C" void svdq_maskset_destroy(svdq_maskset *ms) {
+    if (!ms) return;
+    if (ms->d_numel) (void)hipFree(ms->d_numel);
+    if (ms->d_tile_begin) (void)hipFree(ms->d_tile_begin);
+    if (ms->d_tile_param) (void)hipFree(ms->d_tile_param);
+    free(ms->h_numel);
+    free(ms->h_tile_begin);
+    free(ms);
+}
+
+extern "C" int64_t svdq_maskset_work_bytes(const svdq_maskset *ms) {
+    if (!ms) return 0;
+    return svdq_align_up((int64_t)ms->n_tiles * 4, 256) + svdq_align_up((int64_t)ms->n_tiles * 8, 256) + 256;
+}
+
+__global__ __launch_bounds__(ELT_THREADS) void k_maskset_combine(const int32_t *__restrict__ tile_param,
+                                                                 const int32_t *__restrict__ tile_begin,
+                                                                 const int64_t *__restrict__ numel_tab,
+                                                                 const uint8_t *const *__restrict__ masks, int n_masks,
+                                                                 int strategy, uint8_t *const *__restrict__ outs,
+                                                                 unsigned long long *__restrict__ counts) {
+    const int q = tile_param[blockIdx.x];
+    __shared__ unsigned cnt;
+    combine_tile(masks + (size_t)q * n_masks, n_masks, strategy, blockIdx.x - tile_begin[q], numel_tab[q], outs[q], &cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(&counts[q], (unsigned long long)cnt);
+}
+
+__global__ __launch_bounds__(ELT_THREADS) void k_maskset_count(const int32_t *__restrict__ tile_param,
+                                                               const int32_t *__restrict__ tile_begin,
+                                                               const int64_t *__restrict__ numel_tab,
+                                                               const uint8_t *const *__restrict__ masks,
+                                                               unsigned *__restrict__ tile_counts) {
+    const int q = tile_param[blockIdx.x];
+    const int64_t numel = numel_tab[q];
+    const uint8_t *mask = masks[q];
+    const int64_t base = (int64_t)(blockIdx.x - tile_begin[q]) * MASK_TILE + (int64_t)threadIdx.x * 8;
+    unsigned cnt = 0;
+    for (int e = 0; e < 8; ++e)
+        if (base + e < numel) cnt += mask[base + e] != 0 ? 1u : 0u;
+    __shared__ unsigned s_cnt[ELT_THREADS];
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = s_cnt[0];
+}
+
+// one block per parameter: exclusive scan of ITS tile counts; true / false totals out
+__global__ __launch_bounds__(1024) void k_maskset_scan(const int32_t *__restrict__ tile_begin,
+                                                       const int64_t *__restrict__ numel_tab,
+                                                       const unsigned *__restrict__ tile_counts,
+                                                       unsigned long long *__restrict__ tile_offsets,
+                                                       long long *__restrict__ count_true,
+                                                       long long *__restrict__ count_false) {
+    __shared__ unsigned long long s[1024];
+    __shared__ unsigned long long carry;
+    const int q = blockIdx.x, t0 = tile_begin[q], nt = tile_begin[q + 1] - t0;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nt; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned long long v = i < nt ? tile_counts[t0 + i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            unsigned long long add = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nt) tile_offsets[t0 + i] = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (count_true) count_true[q] = (long long)carry;
+        if (count_false) count_false[q] = (long long)numel_tab[q] - (long long)carry;
+    }
+}
+
+// flat[mask] -> dst_true, flat[~mask] -> dst_false (optional), for n_src buffers per parameter, one pass
+__global__ __launch_bounds__(ELT_THREADS) void k_maskset_scatter(const int32_t *__restrict__ tile_param,
+                                                                 const int32_t *__restrict__ tile_begin,
+                                                                 const int64_t *__restrict__ numel_tab,
+                                                                 const uint8_t *const *__restrict__ masks,
+                                                                 const float *const *__restrict__ src,
+                                                                 float *const *__restrict__ dst_true,
+                                                                 float *const *__restrict__ dst_false, int n_src,
+                                                                 const unsigned long long *__restrict__ tile_offsets) {
+    const int q = tile_param[blockIdx.x];
+    scatter_tile(masks[q], blockIdx.x - tile_begin[q], numel_tab[q], src + (size_t)q * n_src,
+                 dst_true + (size_t)q * n_src, dst_false ? dst_false + (size_t)q * n_src : nullptr, n_src,
+                 tile_offsets[blockIdx.x]);
+}
+
+extern "C" int svdq_maskset_combine(const svdq_maskset *ms, const void *mask_ptrs, int32_t n_masks, int32_t strategy,
+                                    const void *out_ptrs, int64_t *counts, void *stream) {
+    if (!ms || !mask_ptrs || !out_ptrs || !counts) {
+        svdq_set_error("svdq_maskset_combine: bad argument");
+        return SVDQ_EINVAL;
+    }
+    if (n_masks < 1) {
+        svdq_set_error("Empty mask list");
+        return SVDQ_EINVAL;
+    }
+    if (strategy < SVDQ_MASK_UNION || strategy > SVDQ_MASK_MAJORITY) {
+        svdq_set_error("Unknown mask strategy: %d", strategy);
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(int64_t) * ms->n_params, st) != hipSuccess) return SVDQ_EHIP;
+    hipLaunchKernelGGL(k_maskset_combine, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param,
+                       ms->d_tile_begin, ms->d_numel, reinterpret_cast<const uint8_t *const *>(mask_ptrs), n_masks,
+                       strategy, reinterpret_cast<uint8_t *const *>(out_ptrs),
+                       reinterpret_cast<unsigned long long *>(counts));
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+extern "C" int svdq_maskset_compact(const svdq_maskset *ms, const void *mask_ptrs, const void *src_ptrs,
+                                    const void *dst_true_ptrs, const void *dst_false_ptrs, int32_t n_src,
+                                    int64_t *count_true, int64_t *count_false, void *work, void *stream) {
+    if (!ms || !mask_ptrs || !src_ptrs || !dst_true_ptrs || !work || n_src < 1) {
+        svdq_set_error("svdq_maskset_compact: bad argument");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *wb = reinterpret_cast<uint8_t *>(work);
+    unsigned *tile_counts = reinterpret_cast<unsigned *>(wb);
+    unsigned long long *tile_offsets =
+        reinterpret_cast<unsigned long long *>(wb + svdq_align_up((int64_t)ms->n_tiles * 4, 256));
+    auto mp = reinterpret_cast<const uint8_t *const *>(mask_ptrs);
+    hipLaunchKernelGGL(k_maskset_count, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
+                       ms->d_numel, mp, tile_counts);
+    hipLaunchKernelGGL(k_maskset_scan, dim3(ms->n_params), dim3(1024), 0, st, ms->d_tile_begin, ms->d_numel, tile_counts,
+                       tile_offsets, reinterpret_cast<long long *>(count_true),
+                       reinterpret_cast<long long *>(count_false));
+    hipLaunchKernelGGL(k_maskset_scatter, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param,
+                       ms->d_tile_begin, ms->d_numel, mp, reinterpret_cast<const float *const *>(src_ptrs),
+                       reinterpret_cast<float *const *>(dst_true_ptrs),
+                       reinterpret_cast<float *const *>(dst_false_ptrs), n_src, tile_offsets);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }

@@ -32,24 +32,15 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
     groups: Dict[int, List[dict]] = {}
     keep = []
     with torch.cuda.device(dev):
+        masked_by_n: Dict[int, List[tuple]] = {}
         for name in names:
             present = [t for t in tasks if name in task_vectors[t]]
             if not present:
                 continue
             deltas = [task_vectors[t][name] for t in present]
             mask = combined_masks.get(name)
-            if mask is not None and mask.shape == deltas[0].shape:
-                vs, cnt, ka = ml.compact(deltas, mask, invert=False)
-                keep.append(ka)
-                entry = {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": cnt,
-                         "upper": vs[0].numel(), "min": min_size}
-                groups.setdefault(len(present), []).append(entry)
-                if include_noise:
-                    vn, cn, kb = ml.compact(deltas, mask, invert=True)
-                    keep.append(kb)
-                    groups.setdefault(len(present), []).append(
-                        {"name": name, "region": "noise", "tasks": present, "vectors": vn, "count": cn,
-                         "upper": vn[0].numel(), "min": 1})
+            if mask is not None and mask.shape == deltas[0].shape and mask.numel() > 0:
+                masked_by_n.setdefault(len(present), []).append((name, present, deltas, mask))
             else:
                 vs = [prepare_vector(d, dev) for d in deltas]
                 if vs[0].numel() == 0:
@@ -57,6 +48,23 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
                 groups.setdefault(len(present), []).append(
                     {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": None,
                      "upper": vs[0].numel(), "min": 0})
+        # every masked parameter of a group goes through ONE batched compaction (signal and, when asked,
+        # noise in the same pass); mask.sum() stays on the device and becomes rows_dev
+        for n_present, items in masked_by_n.items():
+            ms = ml.MaskSet([it[3].numel() for it in items], dev)
+            dt, df, ct, cf = ms.compact([it[3] for it in items], [it[2] for it in items], want_false=include_noise)
+            keep.append((ms, dt, df))
+            for q, (name, present, _, _) in enumerate(items):
+                groups.setdefault(n_present, []).append(
+                    {"name": name, "region": "masked", "tasks": present, "vectors": dt[q], "count": ct[q:q + 1],
+                     "upper": dt[q][0].numel(), "min": min_size})
+                if include_noise:
+                    groups.setdefault(n_present, []).append(
+                        {"name": name, "region": "noise", "tasks": present, "vectors": df[q], "count": cf[q:q + 1],
+                         "upper": df[q][0].numel(), "min": 1, "gate": ct[q:q + 1]})
+        order = {n: i for i, n in enumerate(names)}
+        for lst in groups.values():
+            lst.sort(key=lambda e: (order[e["name"]], e["region"] != "masked"))
 
         bases: Dict[str, Dict] = {}
         for n_tasks, entries in groups.items():
@@ -76,7 +84,10 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
                         parts.append(torch.tensor([e["upper"]], dtype=torch.int64, device=dev))
                     else:
                         c = e["count"]
-                        parts.append(torch.where(c >= e["min"], c, torch.zeros_like(c)))
+                        ok = c >= e["min"]
+                        if "gate" in e:      # the noise region is only built when the signal region is (cli.py:332-338)
+                            ok = ok & (e["gate"] >= min_size)
+                        parts.append(torch.where(ok, c, torch.zeros_like(c)))
                 rows_dev = torch.cat(parts)
             table = plan.pointer_table([e["vectors"] for e in entries])
             plan.run(table, rows_dev)

@@ -20,6 +20,210 @@ def _as_mask_bytes(m: torch.Tensor, dev) -> torch.Tensor:
     return m.to(dev).contiguous().view(-1).view(torch.uint8)
 
 
+class MaskSet:
+    """A ragged set of masked parameters processed together (svdq_maskset_*): one tile table, a handful of
+    launches for all of them, per-parameter counts kept on the device."""
+
+    def __init__(self, numels, device):
+        from ctypes import byref, c_int64, c_void_p
+        self.lib = nat.lib()
+        self.device = resolve_device(device)
+        self.numels = [int(n) for n in numels]
+        self.Q = len(self.numels)
+        self._h = c_void_p()
+        arr = (c_int64 * self.Q)(*self.numels)
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_create(byref(self._h), self.Q, arr), "svdq_maskset_create")
+        self.work = torch.empty(int(self.lib.svdq_maskset_work_bytes(self._h)), dtype=torch.uint8, device=self.device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            from ctypes import c_void_p
+            self.lib.svdq_maskset_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _table(self, tensors):
+        return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(self.device)
+
+    # prepare_* allocate outputs and upload pointer tables once; run_* only enqueue kernels, so a caller
+    # that compresses the same model repeatedly (or a benchmark) pays no host work per call.
+    def prepare_combine(self, masks_per_param, strategy: str):
+        if strategy not in nat.MASK_STRATEGIES:
+            raise ValueError(f"Unknown mask strategy: {strategy}")
+        n = len(masks_per_param[0])
+        if n < 1:
+            raise ValueError("Empty mask list")
+        flat = [[_as_mask_bytes(m, self.device) for m in ms] for ms in masks_per_param]
+        for q, ms in enumerate(flat):
+            if len(ms) != n or any(m.numel() != self.numels[q] for m in ms):
+                raise ValueError("Shape mismatch: every parameter needs the same number of same-shaped masks")
+        outs = [torch.empty(nq, dtype=torch.uint8, device=self.device) for nq in self.numels]
+        counts = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        self._c = dict(flat=flat, outs=outs, counts=counts, n=n, strategy=nat.MASK_STRATEGIES[strategy],
+                       mt=self._table([m for ms in flat for m in ms]), ot=self._table(outs))
+        return outs, counts
+
+    def run_combine(self):
+        c = self._c
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_combine(self._h, _ptr(c["mt"]), c["n"], c["strategy"], _ptr(c["ot"]),
+                                                    _ptr(c["counts"]), _stream_ptr()), "svdq_maskset_combine")
+
+    def combine(self, masks_per_param, strategy: str):
+        """masks_per_param[q] = list of n per-task bool masks (same n for every q).
+        Returns (combined uint8 byte tensors [numel_q], device int64 counts [Q])."""
+        outs, counts = self.prepare_combine(masks_per_param, strategy)
+        self.run_combine()
+        return outs, counts
+
+    def prepare_compact(self, masks, srcs_per_param, want_false: bool):
+        n_src = len(srcs_per_param[0])
+        mb = [_as_mask_bytes(m, self.device) for m in masks]
+        srcs = [[prepare_vector(v, self.device) for v in vs] for vs in srcs_per_param]
+        for q in range(self.Q):
+            if mb[q].numel() != self.numels[q] or len(srcs[q]) != n_src or any(v.numel() != self.numels[q] for v in srcs[q]):
+                raise ValueError(f"Shape mismatch: tensor vs mask for parameter {q}")
+        dt = [[torch.empty(self.numels[q], dtype=torch.float32, device=self.device) for _ in range(n_src)]
+              for q in range(self.Q)]
+        df = [[torch.empty(self.numels[q], dtype=torch.float32, device=self.device) for _ in range(n_src)]
+              for q in range(self.Q)] if want_false else None
+        ct = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        cf = torch.zeros(self.Q, dtype=torch.int64, device=self.device) if want_false else None
+        self._x = dict(mb=mb, srcs=srcs, n_src=n_src, ct=ct, cf=cf, mt=self._table(mb),
+                       st=self._table([v for vs in srcs for v in vs]), tt=self._table([v for vs in dt for v in vs]),
+                       ft=self._table([v for vs in df for v in vs]) if want_false else None)
+        return dt, df, ct, cf
+
+    def run_compact(self):
+        x = self._x
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_compact(self._h, _ptr(x["mt"]), _ptr(x["st"]), _ptr(x["tt"]), _ptr(x["ft"]),
+                                                    x["n_src"], _ptr(x["ct"]), _ptr(x["cf"]), _ptr(self.work),
+                                                    _stream_ptr()), "svdq_maskset_compact")
+
+    def compact(self, masks, srcs_per_param, want_false: bool):
+        """masks[q]: combined mask; srcs_per_param[q]: list of n_src fp32 tensors of that shape.
+        Returns (dst_true[q][s], dst_false[q][s] | None, count_true [Q], count_false [Q] | None);
+        destination buffers are sized for the worst case, counts stay on the device."""
+        out = self.prepare_compact(masks, srcs_per_param, want_false)
+        self.run_compact()
+        return out
+
+
+def _combine(masks: List[torch.Tensor], strategy: str) -> torch.Tensor:
+    if not masks:
+        raise ValueError("Empty mask list")
+    if strategy not in nat.MASK_STRATEGIES:
+        raise ValueError(f"Unknown mask strategy: {strategy}")
+    shape = masks[0].shape
+    for m in masks[1:]:
+        if m.shape != shape:
+            raise ValueError(f"Shape mismatch: mask {m.shape} vs mask {shape}")
+    out_dev = masks[0].device
+    dev = resolve_device(out_dev if masks[0].is_cuda else "cuda")
+    flat = [_as_mask_bytes(m, dev) for m in masks]
+    numel = flat[0].numel()
+    if numel == 0:
+        return torch.zeros(shape, dtype=torch.bool, device=out_dev)
+    lib = nat.lib()
+    table = torch.tensor([f.data_ptr() for f in flat], dtype=torch.int64).to(dev)
+    out = torch.empty(numel, dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    work = torch.empty(int(lib.svdq_mask_work_bytes(numel)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(lib.svdq_mask_combine(_ptr(table), len(flat), numel, nat.MASK_STRATEGIES[strategy], _ptr(out),
+                                        _ptr(count), _ptr(work), _stream_ptr()), "svdq_mask_combine")
+    return out.view(torch.bool).view(shape).to(out_dev)
+
+
+def compute_union_mask(masks: List[torch.Tensor]) -> torch.Tensor:
+    return _combine(masks, "union")
+
+
+def compute_intersection_mask(masks: List[torch.Tensor]) -> torch.Tensor:
+    return _combine(masks, "intersection")
+
+
+def compute_majority_mask(masks: List[torch.Tensor], threshold: float = 0.5) -> torch.Tensor:
+    if threshold != 0.5:
+        raise ValueError("only the reference's default threshold 0.5 is implemented on the HIP path")
+    return _combine(masks, "majority")
+
+
+def combine_masks(task_masks: Dict[str, Dict[str, torch.Tensor]], strategy: str = "union", device: str = "cpu",
+                  verbose: bool = True) -> Dict[str, torch.Tensor]:
+    """Reference mask_loader.py:488-648: per parameter, combine the masks of the tasks that have it
+    (tasks whose mask dict is None are skipped).  All parameters that have the same number of masks go
+    through ONE batched launch (svdq_maskset_combine)."""
+    if not task_masks:
+        return {}
+    if strategy not in nat.MASK_STRATEGIES:
+        raise ValueError(f"Unknown mask strategy: {strategy}")
+    names = []
+    for pm in task_masks.values():
+        if pm is not None:
+            for n in pm.keys():
+                if n not in names:
+                    names.append(n)
+    per_param = {n: [pm[n] for pm in task_masks.values() if pm is not None and n in pm] for n in names}
+    by_count: Dict[int, List[str]] = {}
+    for n, lst in per_param.items():
+        if lst and lst[0].numel() > 0:
+            by_count.setdefault(len(lst), []).append(n)
+    combined: Dict[str, torch.Tensor] = {}
+    for cnt, group in by_count.items():
+        shape0 = {n: per_param[n][0].shape for n in group}
+        for n in group:
+            for m in per_param[n][1:]:
+                if m.shape != shape0[n]:
+                    raise ValueError(f"Shape mismatch: mask {m.shape} vs mask {shape0[n]}")
+        dev_in = per_param[group[0]][0].device
+        ms = MaskSet([per_param[n][0].numel() for n in group], dev_in if dev_in.type == "cuda" else "cuda")
+        outs, _ = ms.combine([per_param[n] for n in group], strategy)
+        for n, o in zip(group, outs):
+            combined[n] = o.view(torch.bool).view(shape0[n]).to(device if torch.device(device).type == "cuda"
+                                                                     else per_param[n][0].device)
+    for n, lst in per_param.items():          # zero-sized parameters
+        if lst and lst[0].numel() == 0:
+            combined[n] = torch.zeros(lst[0].shape, dtype=torch.bool, device=lst[0].device)
+    if verbose:
+        print(f"   combined masks for {len(combined)} parameters with strategy '{strategy}'")
+    return combined
+
+
+def compact(self, masks, srcs_per_param, want_false: bool):
+        """masks[q]: combined mask; srcs_per_param[q]: list of n_src fp32 tensors of that shape.
+        Returns (dst_true[q][s], dst_false[q][s] | None, count_true [Q], count_false [Q] | None);
+        destination buffers are sized for the worst case, counts stay on the device."""
+        n_src = len(srcs_per_param[0])
+        mb = [_as_mask_bytes(m, self.device) for m in masks]
+        srcs = [[prepare_vector(v, self.device) for v in vs] for vs in srcs_per_param]
+        for q in range(self.Q):
+            if mb[q].numel() != self.numels[q] or len(srcs[q]) != n_src or any(v.numel() != self.numels[q] for v in srcs[q]):
+                raise ValueError(f"Shape mismatch: tensor vs mask for parameter {q}")
+        dt = [[torch.empty(self.numels[q], dtype=torch.float32, device=self.device) for _ in range(n_src)]
+              for q in range(self.Q)]
+        df = [[torch.empty(self.numels[q], dtype=torch.float32, device=self.device) for _ in range(n_src)]
+              for q in range(self.Q)] if want_false else None
+        ct = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        cf = torch.zeros(self.Q, dtype=torch.int64, device=self.device) if want_false else None
+        mt = self._table(mb)
+        st = self._table([v for vs in srcs for v in vs])
+        tt = self._table([v for vs in dt for v in vs])
+        ft = self._table([v for vs in df for v in vs]) if want_false else None
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_compact(self._h, _ptr(mt), _ptr(st), _ptr(tt), _ptr(ft), n_src, _ptr(ct),
+                                                    _ptr(cf), _ptr(self.work), _stream_ptr()), "svdq_maskset_compact")
+        self._keep_x = (mb, srcs, mt, st, tt, ft)
+        return dt, df, ct, cf
+
+
 def _combine(masks: List[torch.Tensor], strategy: str) -> torch.Tensor:
     if not masks:
         raise ValueError("Empty mask list")
