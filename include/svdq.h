@@ -221,6 +221,18 @@ int svdq_reconstruct(const void *u_high_dev, const void *u_low_dev, int32_t u_fp
 int svdq_mask_expand(const float *signal_dev, const float *noise_dev, const uint8_t *mask_dev, int64_t numel,
                      float *out_dev, void *work_dev, void *stream);
 
+/* ---- diagnostics: compute_reconstruction_error (diagnostics.py:72-117).
+ *      recon_dev != NULL: metrics of (orig - recon) for two given vectors.
+ *      recon_dev == NULL: the reconstruction U_high c_high + U_low c_low (+ mean_dev if not NULL; the
+ *      reference's compute_parameter_diagnostics passes none: diagnostics.py:210-212) is formed
+ *      on the fly and never stored.  out6_dev (double[6]) = absolute_error, relative_error,
+ *      max_absolute_error, mean_absolute_error, original_norm, reconstructed_norm.
+ *      work_dev: svdq_recon_error_work_bytes(rows) bytes. */
+int64_t svdq_recon_error_work_bytes(int64_t rows);
+int svdq_recon_error(const void *u_high_dev, const void *u_low_dev, int32_t u_fp16, int64_t rows, int32_t k,
+                     int32_t nl, const float *coef_dev, const float *mean_dev, const float *recon_dev,
+                     const float *orig_dev, double *out6_dev, void *work_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@ from .mask_loader import (combine_masks, compute_union_mask, compute_intersectio
                           apply_mask_to_tensor, get_unmasked_portion, reconstruct_from_masked)
 from .merge import (dequantize_and_average, reconstruct_from_coefficients, merge_parameter, merge_all_parameters,
                     apply_merged_deltas)
+from .diagnostics import compute_reconstruction_error, compute_parameter_diagnostics, compute_all_diagnostics
 from .driver import build_bases, run_basis_and_compress
 from .pipeline import CompressPlan, compress_batch
 

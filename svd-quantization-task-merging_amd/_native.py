@@ -77,6 +77,9 @@ SIGNATURES = {
     "svdq_project_work_bytes": (c_int64, [c_int64, c_int32]),
     "svdq_reconstruct": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                    c_float, c_void_p, c_void_p]),
+    "svdq_recon_error_work_bytes": (c_int64, [c_int64]),
+    "svdq_recon_error": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_mask_expand": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
 }
 

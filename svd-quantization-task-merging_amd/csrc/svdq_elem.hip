@@ -895,3 +895,113 @@ extern "C" int svdq_maskset_compact(const svdq_maskset *ms, const void *mask_ptr
                        reinterpret_cast<float *const *>(dst_false_ptrs), n_src, tile_offsets);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
+
+// ------------------------------------------------------------------------------------ diagnostics
+// compute_reconstruction_error (diagnostics.py:72-117) fused with the reconstruction it is applied to in
+// compute_parameter_diagnostics (diagnostics.py:205-215): rec = U_high c_high + U_low c_low (+ mean when
+// given -- the reference's diagnostics do NOT add it back) is never materialised.
+// out[6] = {||x-rec||, ||x-rec||/||x|| (0 when ||x|| <= 1e-10), max|x-rec|, mean|x-rec|, ||x||, ||rec||}
+struct ErrPart {
+    double se, sx, sr, sa, mx;
+};
+
+template <typename T>
+__global__ __launch_bounds__(ELT_THREADS) void k_recon_error(const T *__restrict__ uh, const T *__restrict__ ul,
+                                                             int64_t rows, int k, int nl,
+                                                             const float *__restrict__ coef,
+                                                             const float *__restrict__ mean,
+                                                             const float *__restrict__ recon_in,
+                                                             const float *__restrict__ orig,
+                                                             ErrPart *__restrict__ part) {
+    __shared__ float c[32];
+    if (threadIdx.x < k + nl) c[threadIdx.x] = coef[threadIdx.x];
+    __syncthreads();
+    double se = 0.0, sx = 0.0, sr = 0.0, sa = 0.0;
+    float mx = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * ELT_THREADS;
+    for (int64_t d = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x; d < rows; d += stride) {
+        float rec;
+        if (recon_in) {
+            rec = recon_in[d];
+        } else {
+            float hi = 0.f, lo = 0.f;
+            for (int i = 0; i < k; ++i) hi = fmaf(u_load(uh, d * k + i), c[i], hi);
+            for (int j = 0; j < nl; ++j) lo = fmaf(u_load(ul, d * nl + j), c[k + j], lo);
+            rec = __fadd_rn(hi, lo);
+            if (mean) rec = __fadd_rn(rec, mean[d]);
+        }
+        const float x = orig[d];
+        const float e = __fsub_rn(x, rec);
+        se += (double)e * e;
+        sx += (double)x * x;
+        sr += (double)rec * rec;
+        sa += fabs((double)e);
+        mx = fmaxf(mx, fabsf(e));
+        if (e != e) mx = e;  // NaN propagates like torch.max
+    }
+    __shared__ double r0[ELT_THREADS], r1[ELT_THREADS], r2[ELT_THREADS], r3[ELT_THREADS], r4[ELT_THREADS];
+    const int tid = threadIdx.x;
+    r0[tid] = se; r1[tid] = sx; r2[tid] = sr; r3[tid] = sa; r4[tid] = (double)mx;
+    __syncthreads();
+    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
+        if (tid < off) {
+            r0[tid] += r0[tid + off]; r1[tid] += r1[tid + off]; r2[tid] += r2[tid + off]; r3[tid] += r3[tid + off];
+            const double a = r4[tid], b = r4[tid + off];
+            r4[tid] = (a != a) ? a : ((b != b) ? b : (b > a ? b : a));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        part[blockIdx.x].se = r0[0]; part[blockIdx.x].sx = r1[0]; part[blockIdx.x].sr = r2[0];
+        part[blockIdx.x].sa = r3[0]; part[blockIdx.x].mx = r4[0];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_recon_error_finish(const ErrPart *__restrict__ part, int nblk, int64_t rows,
+                                                           double *__restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double se = 0.0, sx = 0.0, sr = 0.0, sa = 0.0, mx = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        se += part[b].se; sx += part[b].sx; sr += part[b].sr; sa += part[b].sa;
+        const double v = part[b].mx;
+        mx = (mx != mx) ? mx : ((v != v) ? v : (v > mx ? v : mx));
+    }
+    // the reference works on fp32 tensors: norms are fp32 values
+    const float en = (float)sqrt(se), on = (float)sqrt(sx);
+    out[0] = (double)en;
+    out[1] = on > 1e-10f ? (double)en / (double)on : 0.0;
+    out[2] = mx;
+    out[3] = (double)(float)(sa / (double)rows);
+    out[4] = (double)on;
+    out[5] = (double)(float)sqrt(sr);
+}
+
+extern "C" int64_t svdq_recon_error_work_bytes(int64_t rows) { return (int64_t)project_grid(rows) * sizeof(ErrPart) + 256; }
+
+extern "C" int svdq_recon_error(const void *u_high, const void *u_low, int32_t u_fp16, int64_t rows, int32_t k,
+                                int32_t nl, const float *coef, const float *mean, const float *recon,
+                                const float *orig, double *out6, void *work, void *stream) {
+    const bool fused = recon == nullptr;
+    if (rows < 1 || !orig || !out6 || !work || (fused && (k < 0 || nl < 0 || k + nl > 32 || (k + nl > 0 && !coef) ||
+                                                          (k > 0 && !u_high) || (nl > 0 && !u_low)))) {
+        svdq_set_error("svdq_recon_error: bad argument");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = project_grid(rows);
+    ErrPart *part = reinterpret_cast<ErrPart *>(work);
+    if (!fused) {
+        k = 0;
+        nl = 0;
+    }
+    if (u_fp16 && fused)
+        hipLaunchKernelGGL((k_recon_error<__half>), dim3(grid), dim3(ELT_THREADS), 0, st,
+                           reinterpret_cast<const __half *>(u_high), reinterpret_cast<const __half *>(u_low), rows, k,
+                           nl, coef, mean, recon, orig, part);
+    else
+        hipLaunchKernelGGL((k_recon_error<float>), dim3(grid), dim3(ELT_THREADS), 0, st,
+                           reinterpret_cast<const float *>(u_high), reinterpret_cast<const float *>(u_low), rows, k, nl,
+                           coef, mean, recon, orig, part);
+    hipLaunchKernelGGL(k_recon_error_finish, dim3(1), dim3(64), 0, st, part, grid, rows, out6);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}

@@ -35,6 +35,9 @@
 #ifndef SVDQ_UNROLL_GRAM
 #define SVDQ_UNROLL_GRAM 8
 #endif
+#ifndef SVDQ_UNROLL_GRAM_P1
+#define SVDQ_UNROLL_GRAM_P1 16  // sub-tile loop of the unpacked (N > 8) Gram variants
+#endif
 #ifndef SVDQ_NT_LOADS
 #define SVDQ_NT_LOADS 0
 #endif
@@ -192,7 +195,7 @@ UNROLL_N(SVDQ_UNROLL_GRAM)
             const bool v1ok = (NB == 2) && (16 + c < NTP);
             const float *x0 = X + (v0ok ? c : 0) * XS + 4 * g;
             const float *x1 = X + (v1ok ? 16 + c : 0) * XS + 4 * g;
-#pragma unroll
+UNROLL_N(SVDQ_UNROLL_GRAM_P1)
             for (int j = 0; j < 16; ++j) {
                 f32x4 a0 = *reinterpret_cast<const f32x4 *>(x0 + 16 * j);
                 if (!v0ok) a0 = zero4();

@@ -1,0 +1,146 @@
+"""
+Diagnostics with the reference's dict layout and numbers (reference
+src/svd_hybrid/diagnostics.py:72-321).  The per-task reconstruction error is one fused streaming kernel
+(`svdq_recon_error`: reconstruct and compare without materialising the reconstruction).
+
+Quirk kept on purpose: like the reference, ``compute_parameter_diagnostics`` reconstructs
+WITHOUT adding the mean back (diagnostics.py:210-212) and compares against the uncentred original, so
+``mean_relative_error`` is large whenever ``svd_center`` is on.  A "fixed" number would be a behaviour change.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .pipeline import prepare_vector, resolve_device, _ptr, _stream_ptr
+from .rtvq import RTVQQuantizer, estimate_compression_ratio
+
+_KEYS = ("absolute_error", "relative_error", "max_absolute_error", "mean_absolute_error", "original_norm",
+         "reconstructed_norm")
+
+
+def _metrics(out6: torch.Tensor) -> Dict[str, float]:
+    vals = out6.cpu().tolist()
+    return {k: float(v) for k, v in zip(_KEYS, vals)}
+
+
+def compute_reconstruction_error(original_delta: torch.Tensor, reconstructed_delta: torch.Tensor) -> Dict[str, float]:
+    """Reference diagnostics.py:72-117."""
+    lib = nat.lib()
+    dev = resolve_device(original_delta.device if original_delta.is_cuda else
+                         (reconstructed_delta.device if reconstructed_delta.is_cuda else "cuda"))
+    x = prepare_vector(original_delta, dev)
+    r = prepare_vector(reconstructed_delta, dev)
+    if x.numel() != r.numel():
+        raise ValueError(f"Shape mismatch: original {tuple(original_delta.shape)} vs reconstructed "
+                         f"{tuple(reconstructed_delta.shape)}")
+    n = x.numel()
+    if n == 0:
+        return {k: 0.0 for k in _KEYS}
+    out = torch.empty(6, dtype=torch.float64, device=dev)
+    work = torch.empty(int(lib.svdq_recon_error_work_bytes(n)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(lib.svdq_recon_error(None, None, 0, n, 0, 0, None, None, _ptr(r), _ptr(x), _ptr(out), _ptr(work),
+                                       _stream_ptr()), "svdq_recon_error")
+    return _metrics(out)
+
+
+def _fused_error(x: torch.Tensor, U_high, U_low, c_high, c_low, dev) -> Dict[str, float]:
+    lib = nat.lib()
+    D = x.numel()
+    k = U_high.shape[1] if U_high.dim() == 2 else 0
+    nl = U_low.shape[1] if U_low.dim() == 2 else 0
+    fp16 = (U_high.dtype == torch.float16) if k else (U_low.dtype == torch.float16)
+    dt = torch.float16 if fp16 else torch.float32
+    uh = U_high.to(device=dev, dtype=dt).contiguous() if k else None
+    ul = U_low.to(device=dev, dtype=dt).contiguous() if nl else None
+    coef = torch.cat([c_high.to(dev).float().reshape(-1), c_low.to(dev).float().reshape(-1)]).contiguous()
+    out = torch.empty(6, dtype=torch.float64, device=dev)
+    work = torch.empty(int(lib.svdq_recon_error_work_bytes(D)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(lib.svdq_recon_error(_ptr(uh), _ptr(ul), int(fp16), D, k, nl, _ptr(coef), None, None, _ptr(x),
+                                       _ptr(out), _ptr(work), _stream_ptr()), "svdq_recon_error")
+    return _metrics(out)
+
+
+def compute_parameter_diagnostics(param_name: str, task_vectors: Dict[str, Dict[str, torch.Tensor]],
+                                  compressed_params: Dict[str, Dict], basis: Dict, mask: Optional[torch.Tensor],
+                                  quantizer: RTVQQuantizer, device: str = "cpu") -> Dict:
+    """Reference diagnostics.py:120-231 (same keys, same order of operations, Q1 included)."""
+    from .mask_loader import apply_mask_to_tensor
+    dev = resolve_device(device)
+    diag = {"param_name": param_name, "original_shape": None, "masked_size": 0, "unmasked_size": 0,
+            "reconstruction_errors": {}, "compression_ratios": {}}
+    bm = basis.get("masked")
+    if bm is None:
+        return diag
+    first = next(iter(task_vectors.keys()))
+    if param_name in task_vectors[first]:
+        diag["original_shape"] = list(task_vectors[first][param_name].shape)
+    if mask is not None:
+        diag["masked_size"] = int(mask.sum().item())
+        diag["unmasked_size"] = int((~mask).sum().item())
+    else:
+        diag["masked_size"] = np.prod(diag["original_shape"])
+    diag["basis"] = {"k": bm["k"], "D": bm["D"], "N": bm["N"], "energy_retained": bm["energy_retained"]}
+    errs = []
+    for task in task_vectors.keys():
+        if param_name not in task_vectors[task] or task not in compressed_params:
+            continue
+        delta = task_vectors[task][param_name]
+        if mask is not None and mask.shape == delta.shape:
+            x = apply_mask_to_tensor(delta, mask)
+        else:
+            x = delta.flatten()
+        art = compressed_params[task]
+        if art.get("masked") is None:
+            continue
+        c_high = art["masked"]["c_high_fp16"].to(dev).float()
+        q = art["masked"]["c_low_quant"]
+        c_low = quantizer.dequantize(q, device=dev).float()
+        m = _fused_error(prepare_vector(x, dev), bm["U_high"], bm["U_low"], c_high, c_low, dev)
+        errs.append(m["relative_error"])
+        diag["reconstruction_errors"][task] = m
+        diag["compression_ratios"][task] = estimate_compression_ratio(c_low, q)
+    if errs:
+        diag["mean_relative_error"] = float(np.mean(errs))
+        diag["std_relative_error"] = float(np.std(errs))
+        diag["max_relative_error"] = float(np.max(errs))
+        diag["min_relative_error"] = float(np.min(errs))
+    return diag
+
+
+def compute_all_diagnostics(task_vectors: Dict[str, Dict[str, torch.Tensor]], compressed_all: Dict[str, Dict],
+                            bases: Dict[str, Dict], masks: Dict[str, torch.Tensor], config, device: str = "cpu") -> Dict:
+    """Reference diagnostics.py:234-321."""
+    quantizer = RTVQQuantizer(num_bits=config.svd_low_bits, num_stages=config.svd_rtvq_stages)
+    out = {"config": {"svd_energy_threshold": config.svd_energy_threshold, "svd_max_rank": config.svd_max_rank,
+                      "svd_low_bits": config.svd_low_bits, "svd_rtvq_stages": config.svd_rtvq_stages,
+                      "svd_mask_strategy": config.svd_mask_strategy, "svd_weighting": config.svd_weighting},
+           "per_parameter": {}, "summary": {}}
+    for name in sorted(bases.keys()):
+        if name not in compressed_all:
+            continue
+        out["per_parameter"][name] = compute_parameter_diagnostics(name, task_vectors, compressed_all[name],
+                                                                   bases[name], masks.get(name), quantizer, device)
+    ranks, energies, mean_errs, ratios = [], [], [], []
+    for d in out["per_parameter"].values():
+        if "basis" in d:
+            ranks.append(d["basis"]["k"])
+            energies.append(d["basis"]["energy_retained"])
+        if "mean_relative_error" in d:
+            mean_errs.append(d["mean_relative_error"])
+        if d.get("compression_ratios"):
+            ratios.append(np.mean(list(d["compression_ratios"].values())))
+    out["summary"] = {
+        "num_parameters": len(out["per_parameter"]),
+        "average_rank": float(np.mean(ranks)) if ranks else 0,
+        "std_rank": float(np.std(ranks)) if ranks else 0,
+        "average_energy_retained": float(np.mean(energies)) if energies else 0,
+        "average_reconstruction_error": float(np.mean(mean_errs)) if mean_errs else 0,
+        "average_compression_ratio": float(np.mean(ratios)) if ratios else 0,
+    }
+    return out

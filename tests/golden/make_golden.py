@@ -48,6 +48,7 @@ from src.svd_hybrid import basis as ref_basis                    # noqa: E402
 from src.svd_hybrid import compress as ref_compress              # noqa: E402
 from src.svd_hybrid import merge as ref_merge                    # noqa: E402
 from src.svd_hybrid import mask_loader as ref_masks              # noqa: E402
+from src.svd_hybrid import diagnostics as ref_diag               # noqa: E402
 import quantization_utils as ref_qutils                          # noqa: E402
 
 sys.path.insert(0, ROOT)
@@ -414,6 +415,27 @@ def gen_merge():
     original_shapes = {n: torch.Size(s) for n, s in shapes.items()}
     merged = ref_merge.merge_all_parameters(compressed, bases, masks, weights, original_shapes, cfg, device="cpu",
                                             verbose=False)
+    # diagnostics of the same run (diagnostics.py:72-321; Q1: no mean added back)
+    cfg.svd_mask_strategy = "union"
+    cfg.svd_weighting = "uniform"
+    diag = ref_diag.compute_all_diagnostics(task_vectors, compressed, bases, masks, cfg, device="cpu")
+
+    def plain(o):
+        if isinstance(o, dict):
+            return {k: plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [plain(v) for v in o]
+        if isinstance(o, (np.integer,)):
+            return int(o)
+        if isinstance(o, (np.floating,)):
+            return float(o)
+        return o
+    out["diagnostics_json"] = np.array(json.dumps(plain(diag), sort_keys=True))
+    a, b = task_vectors["T0"]["a.weight"].flatten(), merged["a.weight"].flatten()
+    em = ref_diag.compute_reconstruction_error(a, b)
+    out["err_metrics_T0_vs_merged"] = np.array([em[k] for k in ("absolute_error", "relative_error",
+                                                "max_absolute_error", "mean_absolute_error", "original_norm",
+                                                "reconstructed_norm")], dtype=np.float64)
     base_sd = {n: torch.randn(s, generator=g) for n, s in shapes.items()}
     base_sd["extra.buffer"] = torch.arange(5, dtype=torch.float32)
     final = ref_merge.apply_merged_deltas(base_sd, merged, device="cpu", verbose=False)

@@ -87,3 +87,57 @@ def test_merge_vs_reference_vectors(sq):
     for p in params:
         assert torch.equal(final[p], base[p] + merged[p])
         assert float(np.mean((final[p].cpu().numpy() - g[f"final__{p}"]) ** 2)) <= 1e-6
+
+
+def test_diagnostics_vs_reference_vectors(sq):
+    """compute_all_diagnostics: same dict layout and (Q1 included) the same numbers as the reference."""
+    import json
+    g = load_golden("merge.npz")
+    want = json.loads(str(g["diagnostics_json"]))
+    tasks = [str(t) for t in g["tasks"]]
+    params = [str(p) for p in g["params"]]
+    cfg = sq.SVDHybridConfig(svd_energy_threshold=0.9, svd_max_rank=2, svd_center=True, svd_fp16=True, svd_low_bits=4,
+                             svd_rtvq_stages=2, svd_include_noise=True, svd_min_mask_size=10, svd_noise_shrink=0.5)
+    tv = {t: {} for t in tasks}
+    masks = {}
+    for p in params:
+        shape = g[f"merged__{p}"].shape
+        for i, t in enumerate(tasks):
+            tv[t][p] = torch.from_numpy(g[f"in__{p}"][i]).view(*shape).cuda()
+        if f"mask__{p}" in g:
+            masks[p] = torch.from_numpy(g[f"mask__{p}"]).cuda()
+    bases, comp = sq.run_basis_and_compress(tv, masks, cfg, "cuda")
+    got = sq.compute_all_diagnostics(tv, comp, bases, masks, cfg, device="cuda")
+    assert sorted(got.keys()) == sorted(want.keys()) and got["config"] == want["config"]
+    assert sorted(got["summary"].keys()) == sorted(want["summary"].keys())
+    for key in ("num_parameters", "average_rank", "std_rank"):
+        assert got["summary"][key] == pytest.approx(want["summary"][key])
+    assert got["summary"]["average_energy_retained"] == pytest.approx(want["summary"]["average_energy_retained"], abs=2e-5)
+    # Q1: the mean is not added back, so the error is dominated by ||mean|| / ||x|| -- identical on both sides
+    assert got["summary"]["average_reconstruction_error"] == pytest.approx(
+        want["summary"]["average_reconstruction_error"], rel=2e-2)
+    assert got["summary"]["average_compression_ratio"] == pytest.approx(want["summary"]["average_compression_ratio"])
+    for p in params:
+        gp, wp = got["per_parameter"][p], want["per_parameter"][p]
+        assert sorted(gp.keys()) == sorted(wp.keys())
+        assert gp["original_shape"] == wp["original_shape"] and int(gp["masked_size"]) == int(wp["masked_size"])
+        assert int(gp["unmasked_size"]) == int(wp["unmasked_size"]) and gp["basis"]["k"] == wp["basis"]["k"]
+        assert list(gp["reconstruction_errors"].keys()) == list(wp["reconstruction_errors"].keys()) == tasks
+        for t in tasks:
+            ge, we = gp["reconstruction_errors"][t], wp["reconstruction_errors"][t]
+            assert sorted(ge.keys()) == sorted(we.keys())
+            assert ge["original_norm"] == pytest.approx(we["original_norm"], rel=1e-6)
+            for key in ("absolute_error", "relative_error", "mean_absolute_error", "reconstructed_norm"):
+                assert ge[key] == pytest.approx(we[key], rel=5e-2), (p, t, key)
+            assert gp["compression_ratios"][t] == pytest.approx(wp["compression_ratios"][t])
+    # the two-vector form
+    a = torch.from_numpy(g["in__a.weight"][0]).cuda()
+    b = torch.from_numpy(g["merged__a.weight"]).flatten().cuda()
+    em = sq.compute_reconstruction_error(a, b)
+    want_em = g["err_metrics_T0_vs_merged"]
+    keys = ("absolute_error", "relative_error", "max_absolute_error", "mean_absolute_error", "original_norm",
+            "reconstructed_norm")
+    for key, w in zip(keys, want_em):
+        assert em[key] == pytest.approx(float(w), rel=1e-5), key
+    z = sq.compute_reconstruction_error(torch.zeros(8), torch.ones(8))
+    assert z["relative_error"] == 0 and z["original_norm"] == 0          # ||x|| <= 1e-10 -> 0 (diagnostics.py:107)
