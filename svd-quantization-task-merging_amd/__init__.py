@@ -22,6 +22,9 @@ from .mask_loader import (combine_masks, compute_union_mask, compute_intersectio
 from .merge import (dequantize_and_average, reconstruct_from_coefficients, merge_parameter, merge_all_parameters,
                     apply_merged_deltas)
 from .diagnostics import compute_reconstruction_error, compute_parameter_diagnostics, compute_all_diagnostics
+from .storage import (save_basis, load_basis, save_compressed_coefficients, load_compressed_coefficients,
+                      save_diagnostics, load_diagnostics, save_config, load_config, save_all_artifacts,
+                      load_all_artifacts, save_merged_model, reconstruct_from_artifacts)
 from .driver import build_bases, run_basis_and_compress
 from .pipeline import CompressPlan, compress_batch
 

@@ -141,3 +141,37 @@ def test_diagnostics_vs_reference_vectors(sq):
         assert em[key] == pytest.approx(float(w), rel=1e-5), key
     z = sq.compute_reconstruction_error(torch.zeros(8), torch.ones(8))
     assert z["relative_error"] == 0 and z["original_norm"] == 0          # ||x|| <= 1e-10 -> 0 (diagnostics.py:107)
+
+
+def test_artifacts_reload_end_to_end(sq, tmp_path):
+    """Step 4-9 shape of the reference pipeline on the GPU: compress -> diagnostics -> save_all_artifacts ->
+    reconstruct_from_artifacts (unmasked run, as the reference's reload supports) == in-memory merge."""
+    from oracle import svd_hybrid_oracle as orc
+    tasks = ["A", "B", "C", "D", "E", "F"]
+    shapes = {"enc.w1": (64, 48), "enc.b1": (64,), "enc/w2": (32, 64)}
+    tv = {t: {} for t in tasks}
+    for pi, (n, shp) in enumerate(sorted(shapes.items())):
+        for t, d in zip(tasks, orc.synthetic_deltas(int(np.prod(shp)), len(tasks), 500 + pi)):
+            tv[t][n] = d.view(shp).cuda()
+    cfg = sq.SVDHybridConfig(tasks=tasks, svd_energy_threshold=0.9, svd_max_rank=2, svd_low_bits=4, svd_rtvq_stages=2)
+    bases, comp = sq.run_basis_and_compress(tv, None, cfg, "cuda")
+    diag = sq.compute_all_diagnostics(tv, comp, bases, {}, cfg, device="cuda")
+    weights = {t: 1.0 / len(tasks) for t in tasks}
+    diag["task_weights"] = weights
+    d = str(tmp_path / "art")
+    sq.save_all_artifacts(bases, comp, diag, cfg, d)
+    base = {n: torch.randn(s).cuda() for n, s in shapes.items()}
+    out_path = str(tmp_path / "merged.pt")
+    res = sq.reconstruct_from_artifacts(d, base, out_path, device="cuda")
+    merged = sq.merge_all_parameters(comp, bases, {}, weights, {n: torch.Size(s) for n, s in shapes.items()}, cfg,
+                                     device="cuda", verbose=False)
+    want = sq.apply_merged_deltas(base, merged, device="cuda", verbose=False)
+    assert sorted(res["merged_state_dict"].keys()) == sorted(want.keys())
+    for n in shapes:
+        assert torch.equal(res["merged_state_dict"][n], want[n])
+        exact = sum(weights[t] * tv[t][n] for t in tasks)
+        rel = float((merged[n] - exact).norm() / exact.norm())
+        assert rel < 0.05, (n, rel)
+    saved = torch.load(out_path, weights_only=True)
+    assert torch.equal(saved["enc.w1"].cuda(), want["enc.w1"])
+    assert res["config"] == cfg and "per_parameter" in res["diagnostics"]
