@@ -151,6 +151,42 @@ int svdq_basis_project_range(const svdq_plan *plan, const void *delta_ptrs_dev, 
 int svdq_coeff_quantize_range(const svdq_plan *plan, void *workspace_dev, void *small_dev, int32_t param0,
                               int32_t nparams, void *stream);
 
+/* Uncentred Gram of the CONCATENATED task vectors: out_gram[N*N] (device, fp64, row-major) =
+ * sum over parameters of T_p^T T_p.  Replaces the [N, sum D] host feature matrix of
+ * flatten_task_vectors (src/svd_hybrid/clustering.py:55-120): every quantity cluster_tasks (:198-245)
+ * and compute_cluster_statistics (:263-316) need is a function of these N*N inner products.
+ * Overwrites the pass-1 partials in `workspace`; multi-GPU callers all-reduce out_gram. */
+int svdq_task_gram(const svdq_plan *plan, const void *delta_ptrs, const int64_t *rows_dev, void *workspace,
+                   double *out_gram, void *stream);
+
+/* ---- the step before the path: task-vector ingest and whole-tensor quantization ("TVQ"),
+ * batched over a plan's parameters x tasks.  All pointer tables are DEVICE arrays of device addresses,
+ * parameter-major ([p * n_tasks + t]); fp32 buffers 16-byte aligned, code buffers 4-byte aligned. ---- */
+
+/* delta[p][t] = finetuned[p][t] - base[p] in one pass, base read once for the N tasks.
+ * Replaces compute_task_vector (src/svd_hybrid/task_vector_loader.py:103-141) and the delta loop of
+ * TaskVector.__init__ (task_vectors.py:98-, "delta = finetuned_param - pretrained_param").
+ * base_ptrs: [n_params].  stats_work: NULL, or svdq_tvq_work_bytes() bytes that receive the per-unit
+ * min/max of every delta so that svdq_tvq_quantize(..., stats_ready = 1) skips its statistics pass. */
+int svdq_ingest(const svdq_plan *plan, const void *base_ptrs, const void *finetuned_ptrs, const void *delta_ptrs,
+                void *stats_work, void *stream);
+
+int64_t svdq_tvq_work_bytes(const svdq_plan *plan);
+
+/* Whole-tensor quantization of every (parameter, task) tensor of the plan.
+ * mode 0: asymmetric_quantization (quantization_utils.py:76-99) -> uint8 codes, scale, zero_point;
+ * mode 1: absmax_quantization (quantization_utils.py:60-73)     -> int8 codes, scale.
+ * As used by QuantizedFinetunedModel / QuantizedBaseAndTaskVector (task_vectors.py:764-1010).
+ * scale / zero_point: device float [n_params * n_tasks].  bits in [1, 8] (absmax: [2, 8]). */
+int svdq_tvq_quantize(const svdq_plan *plan, const void *x_ptrs, int32_t mode, int32_t bits, const void *code_ptrs,
+                      float *scale, float *zero_point, void *work, int32_t stats_ready, void *stream);
+
+/* dequantize_asymmetric (quantization_utils.py:137-172) / dequantize_absmax (:102-134, which MULTIPLIES by
+ * the scale -- kept as is), optionally fused with "+ add[p]" (QuantizedTaskVector.apply_to,
+ * task_vectors.py:638-761; QuantizedBaseAndTaskVector.dequantize).  add_ptrs: NULL or [n_params]. */
+int svdq_tvq_dequantize(const svdq_plan *plan, const void *code_ptrs, int32_t mode, const float *scale,
+                        const float *zero_point, const void *add_ptrs, const void *out_ptrs, void *stream);
+
 /* ---- all four stages back to back on one stream (cli.py Step 4 + Step 5 for the batch) ---- */
 int svdq_compress(const svdq_plan *plan, const void *delta_ptrs_dev, const int64_t *rows_dev,
                   void *workspace_dev, void *small_dev, void *basis_dev, float *mean_dev, void *stream);

@@ -104,6 +104,31 @@ def asym_dequantize(q, scale, zp) -> np.ndarray:
     return out.reshape(np.shape(q))
 
 
+def absmax_quantize(x, bits: int = 8) -> Tuple[np.ndarray, np.float32]:
+    """quantization_utils.py:60-73: s = (2^(b-1) - 1) / max|X| (python-int / Tensor = reciprocal * int, two
+    roundings), codes = round(s * X) as int8 (half-to-even; no clamp)."""
+    xf = _f32(x)
+    amax = np.float32(np.max(np.abs(xf)))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = np.float32(np.float32(1.0) / amax) * np.float32(2 ** (bits - 1) - 1)
+        q = np.rint((s * xf).astype(np.float32))
+    return q.astype(np.int8), np.float32(s)
+
+
+def absmax_dequantize(q, scale) -> np.ndarray:
+    """quantization_utils.py:102-134: X_q.float() * scale (the reference multiplies; kept)."""
+    return (np.asarray(q).astype(np.float32) * np.float32(scale)).astype(np.float32)
+
+
+def task_vector(base: Dict[str, np.ndarray], finetuned: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """task_vector_loader.py:103-141: finetuned - base for keys in both with equal shapes (base's order)."""
+    out = {}
+    for k, b in base.items():
+        if k in finetuned and np.shape(finetuned[k]) == np.shape(b):
+            out[k] = np.asarray(finetuned[k]) - np.asarray(b)
+    return out
+
+
 def rtvq_quantize(x, bits: int = 4, stages: int = 2) -> Dict:
     """
     rtvq.py:39-82 + RTVQQuantizer.quantize (rtvq.py:111-126), array form:

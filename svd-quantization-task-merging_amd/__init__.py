@@ -20,11 +20,21 @@ from .compress import (project_to_basis, compress_single_task, compress_masked_r
 from .mask_loader import (combine_masks, compute_union_mask, compute_intersection_mask, compute_majority_mask,
                           apply_mask_to_tensor, get_unmasked_portion, reconstruct_from_masked)
 from .merge import (dequantize_and_average, reconstruct_from_coefficients, merge_parameter, merge_all_parameters,
-                    apply_merged_deltas)
+                    apply_merged_deltas, merge_with_clustering)
+from .weighting import (load_performance_metrics, compute_uniform_weights, compute_performance_weights,
+                        compute_cluster_weights, compute_weights, apply_weights_to_tensors, get_weight_statistics)
+from .clustering import (cluster_tasks, task_gram, cluster_from_gram, cluster_statistics_from_gram,
+                         get_cluster_members, compute_cluster_statistics, merge_by_cluster, merge_cluster_results,
+                         compute_kmeans_clustering, compute_hierarchical_clustering)
 from .diagnostics import compute_reconstruction_error, compute_parameter_diagnostics, compute_all_diagnostics
 from .storage import (save_basis, load_basis, save_compressed_coefficients, load_compressed_coefficients,
                       save_diagnostics, load_diagnostics, save_config, load_config, save_all_artifacts,
                       load_all_artifacts, save_merged_model, reconstruct_from_artifacts)
+from .task_vector_loader import (load_checkpoint, compute_task_vector, compute_task_vectors, load_task_vectors,
+                                 get_parameter_names, organize_by_parameter, flatten_task_deltas,
+                                 get_task_checkpoint_paths)
+from .task_vectors import TaskVector, QuantizedTaskVector, QuantizedFinetunedModel, QuantizedBaseAndTaskVector
+from .ingest import ElementwiseBatch, ingest_state_dicts, quantize_state_dict, dequantize_payloads
 from .driver import build_bases, run_basis_and_compress
 from .pipeline import CompressPlan, compress_batch
 

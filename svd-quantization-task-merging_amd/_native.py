@@ -57,6 +57,12 @@ SIGNATURES = {
     "svdq_basis_project_range": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int32, c_int32, c_void_p]),
     "svdq_coeff_quantize_range": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "svdq_task_gram": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_ingest": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_tvq_work_bytes": (c_int64, [c_void_p]),
+    "svdq_tvq_quantize": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int32, c_void_p]),
+    "svdq_tvq_dequantize": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_compress": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_rtvq_work_bytes": (c_int64, [c_int64]),
     "svdq_rtvq_quantize": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p,

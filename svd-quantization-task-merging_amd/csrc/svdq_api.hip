@@ -286,7 +286,21 @@ extern "C" int svdq_gram_center_range(const svdq_plan *pl, const void *ptrs, con
     int u0, nu;
     unit_range(pl, param0, nparams, &u0, &nu);
     return svdq_launch_gram(pl, ptrs, rows_dev, reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off)), u0, nu,
-                            (hipStream_t)stream);
+                            pl->cfg.center, (hipStream_t)stream);
+}
+
+extern "C" int svdq_task_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                              double *out_gram, void *stream) {
+    if (!pl || !ptrs || !workspace || !out_gram) {
+        svdq_set_error("null argument");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    double *part = reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off));
+    double *part2 = reinterpret_cast<double *>(ws(workspace, pl->ws_gram2_off));
+    if (int rc = svdq_launch_gram(pl, ptrs, rows_dev, part, 0, pl->n_units, /*center=*/0, st)) return rc;
+    if (int rc = svdq_launch_reduce(pl, part, part2, 0, pl->n_params, st)) return rc;
+    return svdq_launch_gram_total(pl, part2, out_gram, st);
 }
 
 extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,

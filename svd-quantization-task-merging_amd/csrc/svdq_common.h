@@ -67,7 +67,8 @@ void svdq_set_error(const char *fmt, ...);
 
 // launchers (defined in the .hip files)
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                     int unit0, int nunits, hipStream_t st);
+                     int unit0, int nunits, int center, hipStream_t st);
+int svdq_launch_gram_total(const svdq_plan *pl, const double *part2, double *out, hipStream_t st);
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
                               double *cpart, int unit0, int nunits, int reverse, hipStream_t st);

@@ -130,19 +130,19 @@ __device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int
 }
 
 // ------------------------------------------------------------------------------------ pass 1
+// One work unit of pass 1 (a run of 256-row blocks of one parameter) by ONE wavefront.
+// X: NTP*XS floats of wave-private LDS.
 template <int NTP>
-__global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ params,
-                                             const SvdqUnit *__restrict__ units,
-                                             const float *const *__restrict__ ptrs,
-                                             const int64_t *__restrict__ rows_dev, int NT, int center,
-                                             double *__restrict__ gram_part, int unit0) {
+__device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *__restrict__ params,
+                                          const SvdqUnit *__restrict__ units,
+                                          const float *const *__restrict__ ptrs,
+                                          const int64_t *__restrict__ rows_dev, int NT, int center,
+                                          double *__restrict__ gram_part) {
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
     constexpr int NACC = (NB == 1) ? 1 : 3;  // AA | AA, AB, BB
-    __shared__ __attribute__((aligned(16))) float X[NTP * XS];
 
-    const int lane = threadIdx.x;
-    const int uidx = unit0 + (int)blockIdx.x;
+    const int lane = threadIdx.x & 63;
     const SvdqUnit ud = units[uidx];
     const int p = ud.param;
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
@@ -255,6 +255,16 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
     }
 }
 
+template <int NTP>
+__global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ params,
+                                             const SvdqUnit *__restrict__ units,
+                                             const float *const *__restrict__ ptrs,
+                                             const int64_t *__restrict__ rows_dev, int NT, int center,
+                                             double *__restrict__ gram_part, int unit0) {
+    __shared__ __attribute__((aligned(16))) float X[NTP * XS];
+    gram_unit<NTP>(X, unit0 + (int)blockIdx.x, params, units, ptrs, rows_dev, NT, center, gram_part);
+}
+
 // ------------------------------------------------------------------------------------ pass 2
 __device__ __forceinline__ void copy_out(const void *lds_src, uint8_t *gdst, int nbytes, int lane) {
     const int nvec = nbytes >> 4;
@@ -298,12 +308,15 @@ __device__ __forceinline__ bf16x8 pack_bf16(const f32x4 &lo, const f32x4 &hi) {
 // rounding correction E^T Xc -- 2^-12 of the signal -- is accumulated here, with bf16 operands on
 // v_mfma_f32_16x16x32_bf16 (K = 32 rows per instruction): bf16's 2^-9 relative operand error on a
 // 2^-12 term is 2^-21 of c, below the fp32 accumulation noise of the direct product.
+// One work unit of pass 2 by ONE wavefront.  X: NTP*XS floats, OUT: SVDQ_BLK_ROWS*NTP + 16 elements of
+// wave-private LDS.
 template <int NTP, bool OUT16>
-__global__ __launch_bounds__(64) void k_basis_project(
-    const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
-    const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
-    const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
-    uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse) {
+__device__ __forceinline__ void bp_unit(
+    float *X, typename OutT<OUT16>::type *OUT, int uidx, const SvdqParam *__restrict__ params,
+    const SvdqUnit *__restrict__ units, const float *const *__restrict__ ptrs,
+    const int64_t *__restrict__ rows_dev, int NT, int center, const float *__restrict__ Wtab,
+    const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev, uint8_t *__restrict__ basis,
+    float *__restrict__ meanbuf, double *__restrict__ cpart) {
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
     constexpr int KS = NTP / 4;
@@ -313,13 +326,7 @@ __global__ __launch_bounds__(64) void k_basis_project(
     constexpr int NPAIR = SVDQ_BLK_ROWS / (2 * TROWS);
     using out_t = typename OutT<OUT16>::type;
 
-    __shared__ __attribute__((aligned(16))) float X[NTP * XS];
-    __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];  // +16: dump slot for idle lanes
-
-    const int lane = threadIdx.x;
-    // units are walked in reverse when asked: pass 1 touched the LAST rows most recently, so they are
-    // the ones still resident in the Infinity Cache
-    const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    const int lane = threadIdx.x & 63;
     const SvdqUnit ud = units[uidx];
     const int p = ud.param;
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
@@ -543,27 +550,41 @@ UNROLL_N(SVDQ_UNROLL_BP)
     }
 }
 
+template <int NTP, bool OUT16>
+__global__ __launch_bounds__(64) void k_basis_project(
+    const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
+    const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
+    const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
+    uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse) {
+    using out_t = typename OutT<OUT16>::type;
+    __shared__ __attribute__((aligned(16))) float X[NTP * XS];
+    __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];  // +16: dump slot for idle lanes
+    const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    bp_unit<NTP, OUT16>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis, meanbuf,
+                        cpart);
+}
+
 // ------------------------------------------------------------------------------------ launchers
 template <int NTP>
 static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                         int unit0, int nunits, hipStream_t st) {
+                         int unit0, int nunits, int center, hipStream_t st) {
     hipLaunchKernelGGL(k_gram<NTP>, dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units,
-                       reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks, pl->cfg.center,
+                       reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks, center,
                        gram_part, unit0);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                     int unit0, int nunits, hipStream_t st) {
+                     int unit0, int nunits, int center, hipStream_t st) {
     switch (pl->ntp) {
-        case 4: return launch_gram_t<4>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
-        case 8: return launch_gram_t<8>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
-        case 12: return launch_gram_t<12>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
-        case 16: return launch_gram_t<16>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
-        case 20: return launch_gram_t<20>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
-        case 24: return launch_gram_t<24>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
-        case 28: return launch_gram_t<28>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
-        case 32: return launch_gram_t<32>(pl, ptrs, rows_dev, gram_part, unit0, nunits, st);
+        case 4: return launch_gram_t<4>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
+        case 8: return launch_gram_t<8>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
+        case 12: return launch_gram_t<12>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
+        case 16: return launch_gram_t<16>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
+        case 20: return launch_gram_t<20>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
+        case 24: return launch_gram_t<24>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
+        case 28: return launch_gram_t<28>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
+        case 32: return launch_gram_t<32>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
     }
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;

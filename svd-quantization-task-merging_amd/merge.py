@@ -3,8 +3,7 @@ Coefficient-space merge on the GPU with the reference's callables (SURVEY.md sec
 reference src/svd_hybrid/merge.py:61-552).  The heavy step -- U c + mean over every row of a
 parameter -- is `svdq_reconstruct` (HBM-bound: reads the fp16 basis once, writes fp32); the masked
 scatter is `svdq_mask_expand`.  Averaging N x N scalars per parameter is host-sized work on small
-device tensors.  Weighting / clustering (weighting.py, clustering.py) stay out of scope: callers pass
-the ``weights`` dict.
+device tensors.  Weights come from weighting.py, cluster labels from clustering.py (Gram-based).
 """
 from __future__ import annotations
 
@@ -126,3 +125,23 @@ def apply_merged_deltas(base_state_dict: Dict[str, torch.Tensor], merged_deltas:
     if verbose:
         print(f"   applied {sum(n in merged_deltas for n in base_state_dict)} merged deltas")
     return out
+
+
+def merge_with_clustering(compressed_all: Dict[str, Dict[str, Dict]], bases: Dict[str, Dict],
+                          masks: Dict[str, torch.Tensor], weights: Dict[str, float],
+                          cluster_assignments: Dict[str, int], original_shapes: Dict[str, torch.Size], config,
+                          device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """Reference merge.py:555-626: merge inside each cluster (weights renormalised over its members), then
+    average the cluster results with softmax(mean member weight) shares (clustering.py:374-425)."""
+    from .clustering import get_cluster_members, merge_cluster_results
+    clusters = get_cluster_members(cluster_assignments)
+    per_cluster, performance = {}, {}
+    for cid, members in clusters.items():
+        w = {m: weights.get(m, 1.0) for m in members}
+        total = sum(w.values())
+        w = {m: v / total for m, v in w.items()}
+        subset = {p: {m: arts[m] for m in members if m in arts} for p, arts in compressed_all.items()}
+        per_cluster[cid] = merge_all_parameters(subset, bases, masks, w, original_shapes, config, device,
+                                                verbose=False)
+        performance[cid] = sum(weights.get(m, 1.0) for m in members) / len(members)
+    return merge_cluster_results(per_cluster, performance, device)

@@ -73,7 +73,8 @@ class CompressPlan:
 
     def __init__(self, rows: Sequence[int], n_tasks: int, *, energy_threshold: float = 0.90,
                  max_rank: Optional[int] = None, center: bool = True, fp16: bool = True,
-                 low_bits: int = 4, rtvq_stages: int = 2, device="cuda", unit_rows: int = 0, flags: int = 0):
+                 low_bits: int = 4, rtvq_stages: int = 2, device="cuda", unit_rows: int = 0, flags: int = 0,
+                 gram_only: bool = False):
         self.lib = nat.lib()
         self.device = resolve_device(device)
         self.rows = [int(x) for x in rows]
@@ -102,8 +103,10 @@ class CompressPlan:
         dev = self.device
         self.workspace = torch.empty(self.sizes.workspace_bytes, dtype=torch.uint8, device=dev)
         self.small = torch.zeros(self.sizes.small_bytes, dtype=torch.uint8, device=dev)
-        self.basis = torch.empty(self.sizes.basis_bytes, dtype=torch.uint8, device=dev)
-        self.mean = torch.empty(self.sizes.mean_floats, dtype=torch.float32, device=dev) if center else None
+        # gram_only: a plan used for svdq_task_gram alone needs no basis / mean storage
+        self.basis = None if gram_only else torch.empty(self.sizes.basis_bytes, dtype=torch.uint8, device=dev)
+        self.mean = (torch.empty(self.sizes.mean_floats, dtype=torch.float32, device=dev)
+                     if center and not gram_only else None)
         self._keep = None
 
     # ---- lifetime
@@ -173,6 +176,13 @@ class CompressPlan:
     def coeff_range(self, p0, n, stream):
         nat.check(self.lib.svdq_coeff_quantize_range(self._h, _ptr(self.workspace), _ptr(self.small), p0, n,
                                                      c_void_p(stream.cuda_stream)), "svdq_coeff_quantize_range")
+
+    def task_gram(self, table, rows_dev=None) -> torch.Tensor:
+        """Uncentred N x N Gram (fp64, device) of the concatenated task vectors of this plan's parameters."""
+        out = torch.empty((self.N, self.N), dtype=torch.float64, device=self.device)
+        nat.check(self.lib.svdq_task_gram(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace), _ptr(out),
+                                          _stream_ptr()), "svdq_task_gram")
+        return out
 
     def run(self, table, rows_dev=None):
         """gram -> eig/rank -> basis+projection -> coefficient quantization, back to back."""

@@ -42,3 +42,12 @@ def gather_small(small: torch.Tensor, group=None) -> List[torch.Tensor]:
     outs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(outs, padded, group=group)
     return [o[:int(s.item())] for o, s in zip(outs, sizes)]
+
+
+def all_reduce_gram(gram: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum the per-rank N x N task Grams (fp64) in place: the only collective of cluster weighting
+    (SURVEY.md 8e-i).  Each rank's Gram covers the parameters it owns; the sum is the Gram of the
+    concatenated task vectors, from which clustering.cluster_from_gram derives the labels on every rank."""
+    import torch.distributed as dist
+    dist.all_reduce(gram, op=dist.ReduceOp.SUM, group=group)
+    return gram

@@ -23,6 +23,10 @@ Fixture families (all .npz, loadable with allow_pickle=False):
   pipeline.npz    cli.py Step 4 + Step 5 loop bodies over 3 layers x 4 tasks
                   (construct_masked_basis + compress_all_parameters), dict layout + numbers
   merge.npz       merge_all_parameters + apply_merged_deltas (merge.py:304-552), 6 tasks, weighted
+  tvq.npz         TaskVector / compute_task_vector and the QuantizedTaskVector family
+                  (task_vectors.py, quantization_utils.py) on a toy state dict x 3 tasks
+  cluster.npz     cluster_tasks / compute_cluster_statistics (clustering.py), compute_weights family
+                  (weighting.py), merge_with_clustering (merge.py:555-626) on merge.npz's inputs
 """
 import json
 import os
@@ -49,7 +53,11 @@ from src.svd_hybrid import compress as ref_compress              # noqa: E402
 from src.svd_hybrid import merge as ref_merge                    # noqa: E402
 from src.svd_hybrid import mask_loader as ref_masks              # noqa: E402
 from src.svd_hybrid import diagnostics as ref_diag               # noqa: E402
+from src.svd_hybrid import clustering as ref_cluster             # noqa: E402
+from src.svd_hybrid import weighting as ref_weighting            # noqa: E402
 import quantization_utils as ref_qutils                          # noqa: E402
+import task_vectors as ref_tv                                    # noqa: E402
+from src.svd_hybrid import task_vector_loader as ref_loader      # noqa: E402
 
 sys.path.insert(0, ROOT)
 from oracle.svd_hybrid_oracle import synthetic_deltas            # noqa: E402  (input generator only)
@@ -454,6 +462,186 @@ def gen_merge():
     save("merge.npz", **out)
 
 
+# ------------------------------------------------------------------------------- ingest / TVQ
+def gen_tvq():
+    """TaskVector.__init__ / compute_task_vector (finetuned - base) and whole-tensor quantization through the
+    reference's QuantizedFinetunedModel / QuantizedBaseAndTaskVector / QuantizedTaskVector."""
+    g = torch.Generator().manual_seed(31)
+    base = {"w1": torch.randn(40, 30, generator=g), "b1": torch.randn(37, generator=g),
+            "w2": 0.5 * torch.randn(64, 33, generator=g), "big": torch.randn(9000, generator=g),
+            "steps": torch.arange(4, dtype=torch.int64), "u8": torch.arange(6, dtype=torch.uint8)}
+    tasks = ["A", "B", "C"]
+    fts = {}
+    for ti, t in enumerate(tasks):
+        ft = {k: (v + 0.01 * (ti + 1) * torch.randn(v.shape, generator=g)) if v.dtype == torch.float32 else v.clone()
+              for k, v in base.items()}
+        fts[t] = ft
+    fts["B"]["b1"] = torch.randn(38, generator=g)        # shape mismatch -> skipped for B
+    del fts["C"]["w2"]                                      # missing -> skipped for C
+    out = {"tasks": np.array(tasks), "keys": np.array(list(base.keys()))}
+    for k, v in base.items():
+        out[f"base__{k}"] = v.numpy()
+    for t in tasks:
+        for k, v in fts[t].items():
+            out[f"ft__{t}__{k}"] = v.numpy()
+        tv = ref_tv.TaskVector(base, fts[t], task_name=t, verbose=False)
+        out[f"tv_keys__{t}"] = np.array(list(tv.vector.keys()))
+        for k, v in tv.vector.items():
+            out[f"tv__{t}__{k}"] = v.numpy()
+        ctv = ref_loader.compute_task_vector(base, fts[t])
+        out[f"ctv_keys__{t}"] = np.array(list(ctv.keys()))
+        for k, v in ctv.items():
+            if v.dtype == torch.float32:
+                assert torch.equal(v, tv.vector[k])
+    tvA = ref_tv.TaskVector(base, fts["A"], task_name="A", verbose=False)
+    s = (tvA + ref_tv.TaskVector(base, fts["B"], task_name="B", verbose=False)) * 0.5
+    out["sum_name"] = np.array(str(s.task_name))
+    out["sum_keys"] = np.array(list(s.vector.keys()))
+    for k, v in s.vector.items():
+        out[f"sum__{k}"] = v.numpy()
+    applied = tvA.apply_to(base, verbose=False)
+    for k, v in applied.items():
+        out[f"applied__{k}"] = v.numpy()
+
+    def store_payloads(prefix, pay):
+        out[f"{prefix}__keys"] = np.array(list(pay.keys()))
+        for k, p in pay.items():
+            out[f"{prefix}__q__{k}"] = p["quantized"].numpy()
+            out[f"{prefix}__scale__{k}"] = p["scale"].numpy()
+            if "zero_point" in p:
+                out[f"{prefix}__zp__{k}"] = p["zero_point"].numpy()
+
+    for method in ("asymmetric", "absmax"):
+        for qbit in (8, 4, 3):
+            tag = f"{method}{qbit}"
+            qf = ref_tv.QuantizedFinetunedModel(fts["A"], qbit=qbit, method=method)
+            store_payloads(f"qf__{tag}", qf.quantized_weights)
+            for k, v in qf.dequantize().items():
+                out[f"qf__{tag}__deq__{k}"] = v.numpy()
+            for k, v in qf.get_task_vector(base).items():
+                out[f"qf__{tag}__tv__{k}"] = v.numpy()
+        qb = ref_tv.QuantizedBaseAndTaskVector(base, tvA, base_qbit=8, task_qbit=4, method=method)
+        store_payloads(f"qb__{method}__base", qb.quantized_base)
+        store_payloads(f"qb__{method}__task", qb.quantized_task)
+        for k, v in qb.dequantize().items():
+            out[f"qb__{method}__deq__{k}"] = v.numpy()
+        qt = ref_tv.QuantizedTaskVector(qb.quantized_task, method=method)
+        for k, v in qt.dequantize().items():
+            out[f"qt__{method}__deq__{k}"] = v.numpy()
+        for k, v in qt.apply_to(base).items():
+            out[f"qt__{method}__applied__{k}"] = v.numpy()
+    save("tvq.npz", **out)
+
+
+# ------------------------------------------------------------------------------- clustering / weighting
+def gen_cluster():
+    """cluster_tasks (clustering.py:198-245), compute_cluster_statistics (:278-316), the compute_weights
+    family (weighting.py:61-396) and merge_with_clustering (merge.py:555-626; inputs = merge.npz's)."""
+    import tempfile
+    out = {}
+    tasks = ["Cars", "DTD", "EuroSAT", "GTSRB", "MNIST", "RESISC45", "SVHN"]
+    shapes = {"a.weight": (96, 64), "a.bias": (96,), "b.weight": (80, 40)}
+    group = [0, 0, 0, 1, 1, 2, 2]   # latent direction each task mostly follows
+    g = torch.Generator().manual_seed(77)
+    tv = {t: {} for t in tasks}
+    for pname, shp in sorted(shapes.items()):
+        n = int(np.prod(shp))
+        dirs = torch.randn(3, n, generator=g)
+        stack = []
+        for ti, t in enumerate(tasks):
+            d = 0.01 * (dirs[group[ti]] * (1.0 + 0.1 * ti) + 0.6 * torch.randn(n, generator=g))
+            if not (pname == "a.bias" and t == "MNIST"):      # one task lacks one parameter (zeros row block)
+                tv[t][pname] = d.view(shp)
+            stack.append(d)
+        out[f"in__{pname}"] = torch.stack(stack).numpy()
+    out["tasks"] = np.array(tasks)
+    out["params"] = np.array(sorted(shapes))
+    out["missing"] = np.array(["MNIST", "a.bias"])
+    for method in ("kmeans", "hierarchical"):
+        for k in (2, 3):
+            a = ref_cluster.cluster_tasks(tv, k, method=method)
+            out[f"labels__{method}__k{k}"] = np.array([a[t] for t in tasks], dtype=np.int64)
+    assign = ref_cluster.cluster_tasks(tv, 3, method="kmeans")
+    st = ref_cluster.compute_cluster_statistics(tv, assign)
+    cids = sorted(st.keys())
+    out["stats__cids"] = np.array(cids, dtype=np.int64)
+    out["stats__size"] = np.array([st[c]["size"] for c in cids], dtype=np.int64)
+    for key in ("mean_distance_to_centroid", "max_distance_to_centroid", "min_distance_to_centroid"):
+        out[f"stats__{key}"] = np.array([st[c][key] for c in cids], dtype=np.float64)
+    # weights
+    acc = {"cars": 0.85, "DTD": 0.72, "euro_sat": 0.93, "GTSRB": 0.99, "MNIST": 0.995, "resisc-45": 0.9}  # SVHN absent
+    with tempfile.TemporaryDirectory() as td:
+        pf = os.path.join(td, "acc.json")
+        with open(pf, "w") as fh:
+            json.dump(acc, fh)
+        out["acc_json"] = np.array(json.dumps(acc))
+        m = ref_weighting.load_performance_metrics(pf, tasks)
+        out["metrics"] = np.array([m[t] for t in tasks], dtype=np.float64)
+        for T in (0.1, 1.0, 5.0):
+            w = ref_weighting.compute_weights(tasks, "performance", performance_file=pf, temperature=T)
+            out[f"w_perf__T{T}"] = np.array([w[t] for t in tasks], dtype=np.float64)
+    w = ref_weighting.compute_weights(tasks, "uniform")
+    out["w_uniform"] = np.array([w[t] for t in tasks], dtype=np.float64)
+    w = ref_weighting.compute_weights(tasks, "cluster", cluster_assignments=assign)
+    out["w_cluster"] = np.array([w[t] for t in tasks], dtype=np.float64)
+    cperf = {0: 0.9, 1: 0.5, 2: 0.7}
+    w = ref_weighting.compute_weights(tasks, "cluster", cluster_assignments=assign, cluster_performance=cperf)
+    out["w_cluster_perf"] = np.array([w[t] for t in tasks], dtype=np.float64)
+    out["cluster_perf"] = np.array([cperf[c] for c in (0, 1, 2)], dtype=np.float64)
+    ws = ref_weighting.get_weight_statistics(w)
+    out["w_stats"] = np.array([ws[k] for k in ("min", "max", "mean", "std", "entropy")], dtype=np.float64)
+    tens = {t: tv[t]["b.weight"] for t in tasks}
+    out["weighted_avg__b.weight"] = ref_weighting.apply_weights_to_tensors(tens, w).numpy()
+    mbc = ref_cluster.merge_by_cluster(tv, assign, w)
+    final = ref_cluster.merge_cluster_results(mbc, cperf)
+    for pname in shapes:
+        out[f"mbc_final__{pname}"] = final[pname].numpy()
+
+    # merge_with_clustering on the merge.npz setting (same seeds as gen_merge)
+    mshapes = {"a.weight": (96, 64), "a.bias": (96,), "b.weight": (80, 40)}
+    mtasks = ["T0", "T1", "T2", "T3", "T4", "T5"]
+    cfg = types.SimpleNamespace(svd_low_bits=4, svd_rtvq_stages=2, svd_include_noise=True, svd_min_mask_size=10,
+                                svd_energy_threshold=0.9, svd_max_rank=2, svd_center=True, svd_fp16=True,
+                                svd_noise_shrink=0.5)
+    weights = {"T0": 0.3, "T1": 0.1, "T2": 0.2, "T3": 0.15, "T4": 0.05, "T5": 0.2}
+    gm = torch.Generator().manual_seed(8)
+    mtv = {t: {} for t in mtasks}
+    for pi, (pname, shp) in enumerate(sorted(mshapes.items())):
+        ds = synthetic_deltas(int(np.prod(shp)), len(mtasks), 300 + pi)
+        for t, d in zip(mtasks, ds):
+            mtv[t][pname] = d.view(shp)
+    masks = {"b.weight": torch.rand(mshapes["b.weight"], generator=gm) > 0.4}
+    bases = {}
+    for pname in sorted(mshapes):
+        mask = masks.get(pname)
+        md, ud = [], []
+        for t in mtasks:
+            delta = mtv[t][pname]
+            if mask is not None:
+                md.append(ref_masks.apply_mask_to_tensor(delta, mask))
+                ud.append(ref_masks.get_unmasked_portion(delta, mask))
+            else:
+                md.append(delta.flatten())
+        basis = ref_basis.construct_masked_basis(md, ud if ud else None, energy_threshold=cfg.svd_energy_threshold,
+                                                 max_rank=cfg.svd_max_rank, center=cfg.svd_center, device="cpu",
+                                                 include_noise=cfg.svd_include_noise)
+        for region in ("masked", "noise"):
+            if basis.get(region) is not None:
+                basis[region]["U_high"] = basis[region]["U_high"].half()
+                basis[region]["U_low"] = basis[region]["U_low"].half()
+        bases[pname] = basis
+    compressed = ref_compress.compress_all_parameters(mtv, masks, bases, cfg, device="cpu")
+    original_shapes = {n: torch.Size(sh) for n, sh in mshapes.items()}
+    massign = {"T0": 0, "T1": 0, "T2": 1, "T3": 1, "T4": 1, "T5": 2}
+    merged = ref_merge.merge_with_clustering(compressed, bases, masks, weights, massign, original_shapes, cfg,
+                                             device="cpu")
+    out["mwc__assign"] = np.array([massign[t] for t in mtasks], dtype=np.int64)
+    for pname in mshapes:
+        assert torch.isfinite(merged[pname]).all()
+        out[f"mwc__{pname}"] = merged[pname].numpy()
+    save("cluster.npz", **out)
+
+
 # ------------------------------------------------------------------------------- rank KATs
 def gen_rank():
     out = {}
@@ -479,6 +667,10 @@ def gen_rank():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # regenerate only the named families, e.g. `make_golden.py cluster`
+        for fam in sys.argv[1:]:
+            globals()["gen_" + fam]()
+        sys.exit(0)
     gen_rtvq()
     gen_rtvq_large()
     gen_rank()
@@ -487,3 +679,5 @@ if __name__ == "__main__":
     gen_masks()
     gen_pipeline()
     gen_merge()
+    gen_cluster()
+    gen_tvq()

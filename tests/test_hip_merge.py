@@ -175,3 +175,98 @@ def test_artifacts_reload_end_to_end(sq, tmp_path):
     saved = torch.load(out_path, weights_only=True)
     assert torch.equal(saved["enc.w1"].cuda(), want["enc.w1"])
     assert res["config"] == cfg and "per_parameter" in res["diagnostics"]
+
+
+# ---------------------------------------------------------------------------- cluster weighting (config #5)
+def _cluster_inputs(g):
+    tasks = [str(t) for t in g["tasks"]]
+    miss_t, miss_p = (str(x) for x in g["missing"])
+    tv = {t: {} for t in tasks}
+    for p in (str(x) for x in g["params"]):
+        X = g[f"in__{p}"]
+        for i, t in enumerate(tasks):
+            if not (t == miss_t and p == miss_p):
+                tv[t][p] = torch.from_numpy(X[i]).cuda()
+    return tv, tasks
+
+
+def test_task_gram_and_cluster_tasks_vs_reference(sq):
+    from test_cluster_cpu import golden_gram, same_partition
+    g = load_golden("cluster.npz")
+    tv, tasks = _cluster_inputs(g)
+    G, names = sq.task_gram(tv, "cuda")
+    assert names == sorted(tasks)
+    Gref, _ = golden_gram(g)
+    # fp32 products summed in fp32 inside a 256-row block, fp64 across blocks
+    np.testing.assert_allclose(G, Gref, rtol=2e-6, atol=2e-6 * np.abs(Gref).max())
+    np.testing.assert_array_equal(G, G.T)
+    for method in ("kmeans", "hierarchical"):
+        for k in (2, 3):
+            lab = sq.cluster_tasks(tv, k, method=method, device="cuda")
+            assert same_partition([lab[t] for t in tasks], g[f"labels__{method}__k{k}"]), (method, k)
+    assign = {t: int(l) for t, l in zip(tasks, g["labels__kmeans__k3"])}
+    st = sq.compute_cluster_statistics(tv, assign, device="cuda")
+    for i, cid in enumerate(g["stats__cids"]):
+        for key in ("mean_distance_to_centroid", "max_distance_to_centroid", "min_distance_to_centroid"):
+            assert st[int(cid)][key] == pytest.approx(float(g[f"stats__{key}"][i]), rel=5e-5, abs=1e-7)
+    with pytest.raises(ValueError, match="Unknown clustering method"):
+        sq.cluster_tasks(tv, 2, method="spectral")
+    # task vectors averaged per cluster, then across clusters (clustering.py:319-425), on the GPU
+    w = {t: float(x) for t, x in zip(tasks, g["w_cluster_perf"])}
+    cperf = {i: float(v) for i, v in enumerate(g["cluster_perf"])}
+    avg = sq.apply_weights_to_tensors({t: tv[t]["b.weight"] for t in tasks}, w)
+    assert avg.is_cuda
+    np.testing.assert_allclose(avg.cpu().numpy().reshape(-1), g["weighted_avg__b.weight"].reshape(-1), rtol=1e-5, atol=1e-8)
+    final = sq.merge_cluster_results(sq.merge_by_cluster(tv, assign, w), cperf)
+    for p in (str(x) for x in g["params"]):
+        np.testing.assert_allclose(final[p].cpu().numpy().reshape(-1), g[f"mbc_final__{p}"].reshape(-1), rtol=1e-5,
+                                   atol=1e-8)
+
+
+def test_task_gram_full_size_linearity(sq):
+    """Size-independent property at ViT-scale rows: Gram(a*X) = a^2 Gram(X), and Gram of a tensor split
+    in two parameters equals the Gram of the whole."""
+    torch.manual_seed(5)
+    N, D = 8, 4096 * 1024 + 333
+    X = [0.01 * torch.randn(D, device="cuda") for _ in range(N)]
+    tv = {f"t{i}": {"w": X[i]} for i in range(N)}
+    G, _ = sq.task_gram(tv, "cuda")
+    cut = 1_000_000
+    tv2 = {f"t{i}": {"a": X[i][:cut].clone(), "b": X[i][cut:].clone()} for i in range(N)}
+    G2, _ = sq.task_gram(tv2, "cuda")
+    tol = 1e-6 * np.abs(G).max()     # off-diagonal entries are ~1e-4 of the diagonal: absolute tolerance
+    np.testing.assert_allclose(G2, G, rtol=1e-6, atol=tol)
+    tv3 = {f"t{i}": {"w": 2.0 * X[i]} for i in range(N)}
+    G3, _ = sq.task_gram(tv3, "cuda")
+    np.testing.assert_array_equal(G3, 4.0 * G)           # scaling by 2 is exact in binary floating point
+    ref = torch.stack(X).double()
+    np.testing.assert_allclose(G, (ref @ ref.T).cpu().numpy(), rtol=2e-6, atol=tol)
+
+
+def test_merge_with_clustering_vs_reference_vectors(sq):
+    g = load_golden("merge.npz")
+    gc = load_golden("cluster.npz")
+    tasks = [str(t) for t in g["tasks"]]
+    params = [str(p) for p in g["params"]]
+    weights = {t: float(w) for t, w in zip(tasks, g["weights"])}
+    cfg = sq.SVDHybridConfig(svd_energy_threshold=0.9, svd_max_rank=2, svd_center=True, svd_fp16=True, svd_low_bits=4,
+                             svd_rtvq_stages=2, svd_include_noise=True, svd_min_mask_size=10, svd_noise_shrink=0.5)
+    tv = {t: {} for t in tasks}
+    masks, shapes = {}, {}
+    for p in params:
+        shape = g[f"merged__{p}"].shape
+        shapes[p] = torch.Size(shape)
+        for i, t in enumerate(tasks):
+            tv[t][p] = torch.from_numpy(g[f"in__{p}"][i]).view(*shape).cuda()
+        if f"mask__{p}" in g:
+            masks[p] = torch.from_numpy(g[f"mask__{p}"]).cuda()
+    bases, comp = sq.run_basis_and_compress(tv, masks, cfg, "cuda")
+    assign = {t: int(c) for t, c in zip(tasks, gc["mwc__assign"])}
+    merged = sq.merge_with_clustering(comp, bases, masks, weights, assign, shapes, cfg, device="cuda")
+    assert sorted(merged.keys()) == sorted(params)
+    for p in params:
+        m = merged[p].cpu().numpy()
+        assert m.shape == gc[f"mwc__{p}"].shape and np.isfinite(m).all()
+        assert float(np.mean((m - gc[f"mwc__{p}"]) ** 2)) <= 1e-6
+        ref = gc[f"mwc__{p}"]
+        assert np.linalg.norm(m - ref) <= 0.25 * np.linalg.norm(ref), p   # same merge, independent 4-bit noise

@@ -22,9 +22,14 @@ def _free_port():
     return port
 
 
+def _same_partition(a, b):
+    return len({(int(x), int(y)) for x, y in zip(a, b)}) == len(set(int(x) for x in a)) == len(set(int(y) for y in b))
+
+
 def _worker(rank, world, port, q):
     import sys
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import svdq_amd
     from svdq_amd import shard, workloads
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -50,6 +55,24 @@ def _worker(rank, world, port, q):
         tot = torch.tensor([float(sum(rows[i] for i in mine))])
         dist.all_reduce(tot)
         assert int(tot.item()) == sum(rows)
+        # cluster weighting: per-rank Gram of the owned parameters, one N*N all-reduce, same labels everywhere
+        from helpers import load_golden
+        from svdq_amd import clustering
+        g = load_golden("cluster.npz")
+        tasks = [str(t) for t in g["tasks"]]
+        pnames = [str(p) for p in g["params"]]
+        cparts = shard.partition_lpt([g[f"in__{p}"].shape[1] for p in pnames], world)
+        G = torch.zeros((len(tasks), len(tasks)), dtype=torch.float64)
+        for i in cparts[rank]:
+            X = g[f"in__{pnames[i]}"].astype(np.float64).copy()
+            if pnames[i] == str(g["missing"][1]):
+                X[tasks.index(str(g["missing"][0]))] = 0.0
+            G += torch.from_numpy(X @ X.T)
+        shard.all_reduce_gram(G)
+        for method in ("kmeans", "hierarchical"):
+            for k in (2, 3):
+                lab = clustering.cluster_from_gram(G.numpy(), tasks, k, method)
+                assert _same_partition([lab[t] for t in tasks], g[f"labels__{method}__k{k}"]), (method, k)
         q.put((rank, "ok", loads))
     except Exception as e:  # surface the failure in the parent
         q.put((rank, f"fail: {e!r}", None))
