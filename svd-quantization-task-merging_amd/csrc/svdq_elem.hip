@@ -24,10 +24,6 @@ struct RtvqPartial {
     double ss;
 };
 
-struct RtvqStage {
-    float scale, zp;
-};
-
 typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void stat_acc(float x, float &mn, float &mx, int &has_nan, double &ss) {
@@ -74,7 +70,17 @@ __global__ __launch_bounds__(ELT_THREADS) void k_rtvq_stats(const float *__restr
     float mn = __builtin_inff(), mx = -__builtin_inff();
     int has_nan = 0;
     double ss = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x; i < nvec; i += stride) {
+    int64_t i = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {  // four independent 16-byte loads in flight per thread
+        f32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const f32x4 *>(x)[i + q * stride];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stat_acc(v[q][e], mn, mx, has_nan, ss);
+    }
+    for (; i < nvec; i += stride) {
         const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) stat_acc(v[e], mn, mx, has_nan, ss);
@@ -83,34 +89,35 @@ __global__ __launch_bounds__(ELT_THREADS) void k_rtvq_stats(const float *__restr
     stats_block_reduce(mn, mx, has_nan, ss, part + blockIdx.x);
 }
 
-// rtvq.py:10-18 for one stage, from the block partials (fixed order => deterministic norm)
-__global__ __launch_bounds__(64) void k_rtvq_params(const RtvqPartial *__restrict__ part, int nblk, int bits,
-                                                    int stage, RtvqStage *__restrict__ stg,
-                                                    float *__restrict__ scale_out, float *__restrict__ zp_out,
-                                                    float *__restrict__ rnorm_out) {
-    if (threadIdx.x != 0) return;
-    float mn = part[0].mn, mx = part[0].mx;
+// rtvq.py:10-18 for one stage, from the block partials of the previous pass.  Every block of the apply
+// kernel recomputes it (<= 2048 partials, L2-resident; fixed order => the same bits in every block and a
+// deterministic norm), which removes a dependent single-block launch per stage.
+__device__ void stage_params(const RtvqPartial *__restrict__ part, int nblk, int bits, float &scale, float &zp,
+                             float &rnorm) {
+    __shared__ RtvqPartial s_tot;
+    float mn = __builtin_inff(), mx = -__builtin_inff();
     int has_nan = 0;
     double ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        mn = part[b].mn < mn ? part[b].mn : mn;
-        mx = part[b].mx > mx ? part[b].mx : mx;
-        has_nan |= part[b].has_nan;
-        ss += part[b].ss;
+    for (int b = threadIdx.x; b < nblk; b += ELT_THREADS) {
+        const RtvqPartial q = part[b];
+        mn = q.mn < mn ? q.mn : mn;
+        mx = q.mx > mx ? q.mx : mx;
+        has_nan |= q.has_nan;
+        ss += q.ss;
     }
-    if (has_nan) {  // torch min/max propagate NaN
+    stats_block_reduce(mn, mx, has_nan, ss, &s_tot);
+    mn = s_tot.mn;
+    mx = s_tot.mx;
+    if (s_tot.has_nan) {  // torch min/max propagate NaN
         mn = __builtin_nanf("");
         mx = mn;
     }
     const float qmax = (float)((1 << bits) - 1);
     // python-int / Tensor == Tensor.reciprocal() * int: two roundings (tests/golden/rtvq_cases.npz)
-    const float scale = __fmul_rn(__fdiv_rn(1.0f, __fsub_rn(mx, mn)), qmax);
-    const float zp = __fmul_rn(-1.0f, rintf(__fmul_rn(scale, mn)));
-    stg[stage].scale = scale;
-    stg[stage].zp = zp;
-    scale_out[stage] = scale;
-    zp_out[stage] = zp;
-    rnorm_out[stage] = (float)sqrt(ss);
+    scale = __fmul_rn(__fdiv_rn(1.0f, __fsub_rn(mx, mn)), qmax);
+    zp = __fmul_rn(-1.0f, rintf(__fmul_rn(scale, mn)));
+    rnorm = (float)sqrt(s_tot.ss);
+    __syncthreads();  // s_tot and the reduction scratch are reused by the caller's own reduction
 }
 
 __device__ __forceinline__ unsigned char quant_one(float x, float scale, float zp, float qmax, float &res) {
@@ -129,17 +136,46 @@ __device__ __forceinline__ unsigned char quant_one(float x, float scale, float z
 
 template <bool LAST>
 __global__ __launch_bounds__(ELT_THREADS) void k_rtvq_apply(const float *__restrict__ rin, float *__restrict__ rout,
-                                                            int64_t n, const RtvqStage *__restrict__ stg, int stage,
-                                                            int bits, uint8_t *__restrict__ codes,
-                                                            RtvqPartial *__restrict__ part) {
-    const float scale = stg[stage].scale, zp = stg[stage].zp;
+                                                            int64_t n, const RtvqPartial *__restrict__ part_in,
+                                                            int nblk_in, int stage, int bits,
+                                                            uint8_t *__restrict__ codes,
+                                                            RtvqPartial *__restrict__ part_out,
+                                                            float *__restrict__ scale_out, float *__restrict__ zp_out,
+                                                            float *__restrict__ rnorm_out) {
+    float scale, zp, rnorm;
+    stage_params(part_in, nblk_in, bits, scale, zp, rnorm);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scale_out[stage] = scale;
+        zp_out[stage] = zp;
+        rnorm_out[stage] = rnorm;
+    }
     const float qmax = (float)((1 << bits) - 1);
     const int64_t nvec = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * ELT_THREADS;
     float mn = __builtin_inff(), mx = -__builtin_inff();
     int has_nan = 0;
     double ss = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x; i < nvec; i += stride) {
+    int64_t i = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const f32x4 *>(rin)[i + q * stride];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 r;
+            u8x4 c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float re;
+                c[e] = quant_one(v[q][e], scale, zp, qmax, re);
+                r[e] = re;
+                if (!LAST) stat_acc(re, mn, mx, has_nan, ss);
+            }
+            reinterpret_cast<u8x4 *>(codes)[i + q * stride] = c;
+            if (!LAST) reinterpret_cast<f32x4 *>(rout)[i + q * stride] = r;
+        }
+    }
+    for (; i < nvec; i += stride) {
         const f32x4 v = reinterpret_cast<const f32x4 *>(rin)[i];
         f32x4 r;
         u8x4 q;
@@ -154,15 +190,15 @@ __global__ __launch_bounds__(ELT_THREADS) void k_rtvq_apply(const float *__restr
         if (!LAST) reinterpret_cast<f32x4 *>(rout)[i] = r;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const int64_t i = (nvec << 2) + threadIdx.x;
+        const int64_t j = (nvec << 2) + threadIdx.x;
         float re;
-        codes[i] = quant_one(rin[i], scale, zp, qmax, re);
+        codes[j] = quant_one(rin[j], scale, zp, qmax, re);
         if (!LAST) {
-            rout[i] = re;
+            rout[j] = re;
             stat_acc(re, mn, mx, has_nan, ss);
         }
     }
-    if (!LAST) stats_block_reduce(mn, mx, has_nan, ss, part + blockIdx.x);
+    if (!LAST) stats_block_reduce(mn, mx, has_nan, ss, part_out + blockIdx.x);
 }
 
 // rtvq.py:85-103: ((0 + deq_0) + deq_1) + ...
@@ -199,8 +235,7 @@ static int rtvq_grid(int64_t n) {
 }
 
 extern "C" int64_t svdq_rtvq_work_bytes(int64_t n) {
-    return svdq_align_up(n * 4, 256) + (int64_t)RTVQ_MAX_BLOCKS * sizeof(RtvqPartial) + SVDQ_MAX_STAGES * sizeof(RtvqStage) +
-           256;
+    return svdq_align_up(n * 4, 256) + 2 * (int64_t)RTVQ_MAX_BLOCKS * sizeof(RtvqPartial) + 256;  // residual + ping-pong partials
 }
 
 extern "C" int svdq_rtvq_quantize(const float *x, int64_t n, int32_t bits, int32_t stages, uint8_t *codes,
@@ -222,19 +257,21 @@ extern "C" int svdq_rtvq_quantize(const float *x, int64_t n, int32_t bits, int32
     hipStream_t st = (hipStream_t)stream;
     uint8_t *wb = reinterpret_cast<uint8_t *>(work);
     float *res = reinterpret_cast<float *>(wb);
-    RtvqPartial *part = reinterpret_cast<RtvqPartial *>(wb + svdq_align_up(n * 4, 256));
-    RtvqStage *stg = reinterpret_cast<RtvqStage *>(part + RTVQ_MAX_BLOCKS);
+    RtvqPartial *part[2];
+    part[0] = reinterpret_cast<RtvqPartial *>(wb + svdq_align_up(n * 4, 256));
+    part[1] = part[0] + RTVQ_MAX_BLOCKS;
     const int grid = rtvq_grid(n);
-    hipLaunchKernelGGL(k_rtvq_stats, dim3(grid), dim3(ELT_THREADS), 0, st, x, n, part);
+    // 1 + S launches: statistics of x, then per stage "parameters (recomputed per block) + codes + residual +
+    // statistics of the residual"
+    hipLaunchKernelGGL(k_rtvq_stats, dim3(grid), dim3(ELT_THREADS), 0, st, x, n, part[0]);
     for (int s = 0; s < stages; ++s) {
-        hipLaunchKernelGGL(k_rtvq_params, dim3(1), dim3(64), 0, st, part, grid, bits, s, stg, scale, zp, rnorm);
         const float *rin = (s == 0) ? x : res;
         if (s == stages - 1)
-            hipLaunchKernelGGL((k_rtvq_apply<true>), dim3(grid), dim3(ELT_THREADS), 0, st, rin, res, n, stg, s, bits,
-                               codes + (size_t)s * code_stride, part);
+            hipLaunchKernelGGL((k_rtvq_apply<true>), dim3(grid), dim3(ELT_THREADS), 0, st, rin, res, n, part[s & 1], grid,
+                               s, bits, codes + (size_t)s * code_stride, part[(s + 1) & 1], scale, zp, rnorm);
         else
-            hipLaunchKernelGGL((k_rtvq_apply<false>), dim3(grid), dim3(ELT_THREADS), 0, st, rin, res, n, stg, s, bits,
-                               codes + (size_t)s * code_stride, part);
+            hipLaunchKernelGGL((k_rtvq_apply<false>), dim3(grid), dim3(ELT_THREADS), 0, st, rin, res, n, part[s & 1], grid,
+                               s, bits, codes + (size_t)s * code_stride, part[(s + 1) & 1], scale, zp, rnorm);
     }
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }

@@ -250,7 +250,27 @@ __global__ __launch_bounds__(64) void k_tvq_dequant(const SvdqParam *__restrict_
         const uint8_t *c = code_ptrs[(size_t)p * NT + t];
         float *o = out_ptrs[(size_t)p * NT + t];
         const float scale = scale_in[(size_t)p * NT + t], zp = mode == 0 ? zp_in[(size_t)p * NT + t] : 0.f;
-        for (int64_t i = r0 + 4 * lane; i < v1; i += 256) {
+        int64_t i = r0 + 4 * lane;
+        for (; i + 768 < v1; i += 1024) {  // 4 code words (and addends) in flight per lane
+            u8x4 q[4];
+            f32x4 a[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                q[w] = *AS1(u8x4, c + i + 256 * w);
+                if (add) a[w] = *AS1(f32x4, add + i + 256 * w);
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = tvq_value(q[w][e], scale, zp, mode);
+                    if (add) v[e] = __fadd_rn(a[w][e], v[e]);
+                }
+                *reinterpret_cast<f32x4 *>(o + i + 256 * w) = v;
+            }
+        }
+        for (; i < v1; i += 256) {
             const u8x4 q = *AS1(u8x4, c + i);
             f32x4 v;
 #pragma unroll

@@ -60,14 +60,31 @@ int svdq_launch_reduce(const svdq_plan *pl, const double *part, double *part2, i
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
-// Sum of the level-2 partials over all parameters and chunks, fixed order (one thread per entry).
-__global__ __launch_bounds__(64) void k_gram_total(int nparams, int nn, const double *__restrict__ part2,
-                                                   double *__restrict__ out) {
-    for (int e = threadIdx.x; e < nn; e += 64) out[e] = chunk_sum(part2, 0, nparams * SVDQ_RC, nn, e);
+// Sum of the level-2 partials over all parameters and chunks, fixed order: 256 threads, thread j of an
+// entry's group takes partials j, j+G, ... (chunk_sum order within), then a fixed tree over the group.
+__global__ __launch_bounds__(256) void k_gram_total(int nparams, int nn, const double *__restrict__ part2,
+                                                    double *__restrict__ out) {
+    __shared__ double red[256];
+    const int total = nparams * SVDQ_RC;
+    for (int e0 = 0; e0 < nn; e0 += 16) {   // 16 entries x 16 partial-sums per pass
+        const int e = e0 + (threadIdx.x & 15), j = threadIdx.x >> 4;
+        const int per = (total + 15) / 16;
+        int a = j * per, b = a + per;
+        if (b > total) b = total;
+        if (a > b) a = b;
+        red[threadIdx.x] = e < nn ? chunk_sum(part2, a, b, nn, e) : 0.0;
+        __syncthreads();
+        for (int off = 128; off >= 16; off >>= 1) {
+            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x < 16 && e < nn) out[e] = red[threadIdx.x];
+        __syncthreads();
+    }
 }
 
 int svdq_launch_gram_total(const svdq_plan *pl, const double *part2, double *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_gram_total, dim3(1), dim3(64), 0, st, pl->n_params, pl->n_tasks * pl->n_tasks, part2, out);
+    hipLaunchKernelGGL(k_gram_total, dim3(1), dim3(256), 0, st, pl->n_params, pl->n_tasks * pl->n_tasks, part2, out);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
