@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--unit-rows", type=int, default=0)
     ap.add_argument("--pipeline-lag", type=int, default=2, help="groups of gram issued ahead of basis_project")
     ap.add_argument("--pipeline-in-c", action="store_true", help="run the pipelined schedule inside svdq_compress")
+    ap.add_argument("--fused", action="store_true",
+                    help="fused schedule: gram + eig + basis_project in ONE launch (atomic item queue, ready flags)")
+    ap.add_argument("--fused-lag-mb", type=int, default=0, help="MB of Gram work queued between the two passes of a tensor")
     ap.add_argument("--pipeline-mb", type=float, default=0.0,
                     help="experimental: group parameters into >= this many MB of input and pipeline "
                          "gram(g+1) | eig(g) on a side stream | basis_project(g) so a group's deltas are still "
@@ -170,6 +173,8 @@ def main():
     flags = 0
     if args.pipeline_mb > 0 and args.pipeline_in_c:
         flags = (int(args.pipeline_mb) << 8) | ((args.pipeline_lag & 0xf) << 4)
+    if args.fused:
+        flags = 4 | (int(args.fused_lag_mb) << 8)
     plan = CompressPlan(rows, N, energy_threshold=args.energy, max_rank=64, center=True, fp16=True,
                         low_bits=args.bits, rtvq_stages=args.stages, device=dev, unit_rows=args.unit_rows,
                         flags=flags)
@@ -237,7 +242,7 @@ def main():
             return
         if groups:
             step_pipelined()
-        elif events is None or args.pipeline_in_c:
+        elif events is None or args.pipeline_in_c or args.fused:
             plan.run(table)
         else:
             events[0].record(); plan.gram_center(table)
@@ -274,7 +279,7 @@ def main():
 
     # per-kernel HIP-event times (this rank), averaged over the timed steps
     kms = [0.0] * 4
-    if not groups and not args.pipeline_in_c and mset is None:
+    if not groups and not args.pipeline_in_c and not args.fused and mset is None:
         for s in range(args.steps):
             for i in range(4):
                 kms[i] += ev[s][i].elapsed_time(ev[s][i + 1])
@@ -303,7 +308,7 @@ def main():
                                    f"sum D = {int(sumD)}/GPU, energy {args.energy}, center, fp16 bases, "
                                    f"{args.bits}-bit x {args.stages}-stage RTVQ",
                        "tensors_per_gpu": len(rows), "tasks": N, "mean_rank_k": round(k_mean, 2),
-                       "units": int(plan.sizes.n_units), "pipeline_groups": len(groups),
+                       "units": int(plan.sizes.n_units), "pipeline_groups": len(groups), "schedule": "fused" if args.fused else "4 launches",
                        "masks": args.masks, "mask_density": (round(float(sm.rows.sum()) / sumD, 4)
                                                              if args.masks != "none" else None),
                        "sharding": "none" if world == 1 else (

@@ -50,8 +50,12 @@ typedef struct svdq_config {
     int32_t low_bits;          /* svd_low_bits 1..8                                  */
     int32_t rtvq_stages;       /* svd_rtvq_stages 1..SVDQ_MAX_STAGES                 */
     int32_t unit_rows;         /* 0 = auto; rows per work unit (multiple of 256)     */
-    int32_t reserved;          /* schedule bits, 0 = four whole-batch launches.  bits 8..23: group size in MB for
-                                  the cache-resident pipeline of svdq_compress; bits 4..7: its lag (default 2)  */
+    int32_t reserved;          /* schedule bits of svdq_compress, 0 = four whole-batch launches.
+                                  bit 2: fused persistent schedule (one launch for gram + eig + basis_project with
+                                         in-memory ready flags; bits 8..23 = lag in MB between the two passes of a
+                                         parameter, 0 = default);
+                                  else bits 8..23: group size in MB of the multi-stream pipeline, bits 4..7 its lag;
+                                  bit 0: reverse unit order in pass 2.  Results are bit-identical in every mode. */
 } svdq_config;
 
 /* Byte sizes / strides the caller needs to allocate outputs (all device memory). */
@@ -79,6 +83,7 @@ typedef struct svdq_small_layout {
     int64_t zp_off;         /* float   [P][N][S]                                                   */
     int64_t rnorm_off;      /* float   [P][N][S]    residual norm before each stage                */
     int64_t coef_off;       /* float   [P][N][N]    fp32 coefficients c[t][i] before rounding      */
+    int64_t status_off;     /* int32   [1]          written by svdq_compress: 0 = ok, 1 = fused schedule timed out */
     int64_t total_bytes;
 } svdq_small_layout;
 

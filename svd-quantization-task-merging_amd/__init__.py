@@ -18,7 +18,8 @@ from .basis import (construct_basis, construct_masked_basis, select_rank, comput
 from .compress import (project_to_basis, compress_single_task, compress_masked_regions, compress_parameter,
                        compress_all_parameters)
 from .mask_loader import (combine_masks, compute_union_mask, compute_intersection_mask, compute_majority_mask,
-                          apply_mask_to_tensor, get_unmasked_portion, reconstruct_from_masked)
+                          apply_mask_to_tensor, get_unmasked_portion, reconstruct_from_masked, load_task_masks,
+                          load_single_mask, load_tall_mask_file, state_dict_to_vector, vector_to_state_dict)
 from .merge import (dequantize_and_average, reconstruct_from_coefficients, merge_parameter, merge_all_parameters,
                     apply_merged_deltas, merge_with_clustering)
 from .weighting import (load_performance_metrics, compute_uniform_weights, compute_performance_weights,
@@ -26,7 +27,9 @@ from .weighting import (load_performance_metrics, compute_uniform_weights, compu
 from .clustering import (cluster_tasks, task_gram, cluster_from_gram, cluster_statistics_from_gram,
                          get_cluster_members, compute_cluster_statistics, merge_by_cluster, merge_cluster_results,
                          compute_kmeans_clustering, compute_hierarchical_clustering)
-from .diagnostics import compute_reconstruction_error, compute_parameter_diagnostics, compute_all_diagnostics
+from .diagnostics import (compute_reconstruction_error, compute_parameter_diagnostics, compute_all_diagnostics,
+                          compute_compression_statistics, print_detailed_compression_report,
+                          print_diagnostics_summary)
 from .storage import (save_basis, load_basis, save_compressed_coefficients, load_compressed_coefficients,
                       save_diagnostics, load_diagnostics, save_config, load_config, save_all_artifacts,
                       load_all_artifacts, save_merged_model, reconstruct_from_artifacts)
@@ -37,6 +40,7 @@ from .task_vectors import TaskVector, QuantizedTaskVector, QuantizedFinetunedMod
 from .ingest import ElementwiseBatch, ingest_state_dicts, quantize_state_dict, dequantize_payloads
 from .driver import build_bases, run_basis_and_compress
 from .pipeline import CompressPlan, compress_batch
+from . import cli
 
 # aliases named by BASELINE.json's north_star (quantization_utils.py)
 dequantize_asymmetric = asymmetric_dequantization

@@ -35,7 +35,7 @@ class SvdqSizes(Structure):
 class SvdqSmallLayout(Structure):
     _fields_ = [(n, c_int64) for n in ("sigma_off", "k_off", "r_off", "energy_off", "rows_off",
                                        "chigh_off", "codes_off", "scale_off", "zp_off", "rnorm_off",
-                                       "coef_off", "total_bytes")]
+                                       "coef_off", "status_off", "total_bytes")]
 
 
 # name -> (restype, argtypes); mirrors include/svdq.h one to one (tests check the export list)

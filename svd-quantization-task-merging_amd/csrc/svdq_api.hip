@@ -160,11 +160,61 @@ extern "C" int svdq_plan_create(svdq_plan **out, int32_t n_tasks, int32_t n_para
     L.zp_off = off;     off += svdq_align_up(P * N * S * 4, 64);
     L.rnorm_off = off;  off += svdq_align_up(P * N * S * 4, 64);
     L.coef_off = off;   off += svdq_align_up(P * nn * 4, 64);
+    L.status_off = off; off += 64;
     L.total_bytes = off;
     pl->sizes.small_bytes = off;
 
+    // fused persistent schedule: the item queue.  Gram items in parameter order; the projection items of a
+    // parameter become eligible once `lag` bytes of Gram work have been queued after the parameter's last Gram
+    // item (time for its eigen-stage), and are then interleaved one (two when many wait) per Gram item.
+    pl->fused = (cfg->reserved >> 2) & 1;
+    if (pl->fused) {
+        int64_t lag = (int64_t)((cfg->reserved >> 8) & 0xffff) * 1000000;
+        if (lag <= 0) lag = 192 * 1000000LL;
+        pl->n_items = 2 * pl->n_units;
+        int32_t *items = (int32_t *)malloc(sizeof(int32_t) * (size_t)pl->n_items);
+        int32_t *bq = (int32_t *)malloc(sizeof(int32_t) * (size_t)pl->n_units);   // FIFO of eligible projection units
+        int64_t *done_pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_params);
+        int64_t pos = 0;
+        int n = 0, bq_head = 0, bq_tail = 0, next_pending = 0;  // parameters [next_pending, p) wait for their lag
+        for (int p = 0; p < n_params; ++p) {
+            const SvdqParam &pd = pl->h_params[p];
+            for (int32_t i = 0; i < pd.unit_count; ++i) {
+                const int32_t u = pd.unit_begin + i;
+                items[n++] = u;
+                pos += (int64_t)pl->h_units[u].nrows * N * 4;
+                while (next_pending < p && pos - done_pos[next_pending] >= lag) {
+                    const SvdqParam &q = pl->h_params[next_pending++];
+                    for (int32_t j = 0; j < q.unit_count; ++j) bq[bq_tail++] = q.unit_begin + j;
+                }
+                if (bq_head < bq_tail) items[n++] = (int32_t)(0x80000000u | (uint32_t)bq[bq_head++]);
+                if (bq_tail - bq_head > 256) items[n++] = (int32_t)(0x80000000u | (uint32_t)bq[bq_head++]);
+            }
+            done_pos[p] = pos;
+        }
+        while (next_pending < n_params) {
+            const SvdqParam &q = pl->h_params[next_pending++];
+            for (int32_t j = 0; j < q.unit_count; ++j) bq[bq_tail++] = q.unit_begin + j;
+        }
+        while (bq_head < bq_tail) items[n++] = (int32_t)(0x80000000u | (uint32_t)bq[bq_head++]);
+        free(bq);
+        free(done_pos);
+        pl->ctl_bytes = (int64_t)sizeof(int32_t) * (4 + (int64_t)n_params * (SVDQ_RC + 2));
+        hipError_t fe = (n == pl->n_items) ? hipSuccess : hipErrorUnknown;
+        if (fe == hipSuccess) fe = hipMalloc((void **)&pl->d_items, sizeof(int32_t) * (size_t)pl->n_items);
+        if (fe == hipSuccess) fe = hipMalloc((void **)&pl->d_ctl, (size_t)pl->ctl_bytes);
+        if (fe == hipSuccess)
+            fe = hipMemcpy(pl->d_items, items, sizeof(int32_t) * (size_t)pl->n_items, hipMemcpyHostToDevice);
+        free(items);
+        if (fe != hipSuccess) {
+            svdq_set_error("fused schedule setup failed: %s", hipGetErrorString(fe));
+            svdq_plan_destroy(pl);
+            return SVDQ_EHIP;
+        }
+    }
+
     // cache-resident pipeline: groups of consecutive parameters with >= group_mb MB of input
-    const int group_mb = (cfg->reserved >> 8) & 0xffff;
+    const int group_mb = pl->fused ? 0 : (cfg->reserved >> 8) & 0xffff;
     pl->lag = (cfg->reserved >> 4) & 0xf;
     if (pl->lag < 1) pl->lag = 2;
     if (group_mb > 0) {
@@ -220,6 +270,8 @@ extern "C" void svdq_plan_destroy(svdq_plan *pl) {
     if (!pl) return;
     if (pl->d_params) (void)hipFree(pl->d_params);
     if (pl->d_units) (void)hipFree(pl->d_units);
+    if (pl->d_items) (void)hipFree(pl->d_items);
+    if (pl->d_ctl) (void)hipFree(pl->d_ctl);
     for (int g = 0; g < pl->n_groups; ++g) {
         if (pl->ev_gram && pl->ev_gram[g]) (void)hipEventDestroy(pl->ev_gram[g]);
         if (pl->ev_eig && pl->ev_eig[g]) (void)hipEventDestroy(pl->ev_eig[g]);
@@ -415,8 +467,36 @@ static int compress_pipelined(const svdq_plan *pl, const void *ptrs, const int64
     return svdq_coeff_quantize(pl, workspace, small, main);
 }
 
+// One persistent launch for gram + eig + basis_project (k_fused), then the coefficient epilogue.
+static int compress_fused(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, void *small,
+                          void *basis, float *mean, hipStream_t st) {
+    if (!ptrs || !workspace || !small || !basis) {
+        svdq_set_error("null argument");
+        return SVDQ_EINVAL;
+    }
+    if ((reinterpret_cast<uintptr_t>(basis) & 255) != 0) {
+        svdq_set_error("basis buffer must be 256-byte aligned");
+        return SVDQ_EINVAL;
+    }
+    uint8_t *sm = reinterpret_cast<uint8_t *>(small);
+    HIP_TRY(hipMemsetAsync(pl->d_ctl, 0, (size_t)pl->ctl_bytes, st));
+    int rc = svdq_launch_fused(pl, ptrs, rows_dev, reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off)),
+                               reinterpret_cast<double *>(ws(workspace, pl->ws_gram2_off)),
+                               reinterpret_cast<float *>(ws(workspace, pl->ws_w_off)),
+                               reinterpret_cast<double *>(ws(workspace, pl->ws_c0_off)), sm,
+                               reinterpret_cast<uint8_t *>(basis), mean,
+                               reinterpret_cast<double *>(ws(workspace, pl->ws_cpart_off)), st);
+    if (rc != SVDQ_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(sm + pl->small.status_off, pl->d_ctl + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return svdq_coeff_quantize(pl, workspace, small, st);
+}
+
 extern "C" int svdq_compress(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
                              void *small, void *basis, float *mean, void *stream) {
+    if (pl && pl->fused) return compress_fused(pl, ptrs, rows_dev, workspace, small, basis, mean, (hipStream_t)stream);
+    if (pl && small)
+        HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(small) + pl->small.status_off, 0, sizeof(int32_t),
+                               (hipStream_t)stream));
     if (pl && pl->n_groups > 1)
         return compress_pipelined(pl, ptrs, rows_dev, workspace, small, basis, mean, (hipStream_t)stream);
     int rc = svdq_gram_center(pl, ptrs, rows_dev, workspace, stream);

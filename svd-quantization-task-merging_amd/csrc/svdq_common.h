@@ -56,6 +56,11 @@ struct svdq_plan {
     hipEvent_t *ev_gram, *ev_eig, *ev_bp, ev_start;
     hipStream_t gram_stream;
     hipStream_t side[SVDQ_NSIDE];
+    // optional fused persistent schedule (cfg.reserved bit 2; bits 8..23 = lag in MB between the Gram and the
+    // projection of a parameter): item queue and the zero-initialised control block
+    int32_t fused, n_items;
+    int32_t *d_items, *d_ctl;
+    int64_t ctl_bytes;
 };
 
 __host__ __device__ static inline int64_t svdq_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -72,6 +77,9 @@ int svdq_launch_gram_total(const svdq_plan *pl, const double *part2, double *out
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
                               double *cpart, int unit0, int nunits, int reverse, hipStream_t st);
+int svdq_launch_fused(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
+                      double *gram_part2, float *W, double *c0, uint8_t *small, uint8_t *basis, float *mean,
+                      double *cpart, hipStream_t st);
 int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W,
                     double *c0, uint8_t *small, int param0, int nparams, hipStream_t st);
 int svdq_launch_reduce(const svdq_plan *pl, const double *part, double *part2, int param0, int nparams,

@@ -11,6 +11,7 @@
 // roots on the critical path of every round); ORTHOGONALITY must hold to fp64, so c = (1+t^2)^-1/2 is
 // refined by Newton steps in fp64 and s = t c.
 __device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double &cs, double &sn) {
+#pragma clang fp contract(off)  // same bits whichever translation unit (and -ffp-contract) this is inlined into
     cs = 1.0;
     sn = 0.0;
     if (apq == 0.0) return;
@@ -56,6 +57,7 @@ __device__ __forceinline__ void phase_sync() {
 // Canonical fixed-order sum of partial slots [a, b) for entry e: eight interleaved accumulators, then a
 // fixed tree.  k_reduce and the fused kernel both use it, so the two schedules give identical bits.
 __device__ __forceinline__ double chunk_sum(const double *__restrict__ part, int a, int b, int nn, int e) {
+#pragma clang fp contract(off)
     double acc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[u] = 0.0;
@@ -78,6 +80,7 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
                           double *__restrict__ c0_out, float *__restrict__ sigma_out, int32_t *__restrict__ k_out,
                           int32_t *__restrict__ r_out, float *__restrict__ energy_out,
                           int64_t *__restrict__ rows_out) {
+#pragma clang fp contract(off)
     constexpr int LDX = NMAX + 1;      // padded leading dimension
     double *Gd = lds;                  // [NMAX*NMAX] (deflated) Gram, kept for the completion column
     double *A = Gd + NMAX * NMAX;      // [NMAX*LDX] working matrix, later W in fp64

@@ -26,6 +26,7 @@
 // Accumulation: fp32 inside a block (64 MFMA k-steps), fp64 across blocks and units.
 
 #include "svdq_common.h"
+#include "svdq_eig.h"
 #include <hip/hip_fp16.h>
 
 #define XS SVDQ_XS
@@ -562,6 +563,183 @@ __global__ __launch_bounds__(64) void k_basis_project(
     const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
     bp_unit<NTP, OUT16>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis, meanbuf,
                         cpart);
+}
+
+// ------------------------------------------------------------------------------------ fused schedule
+// One launch for gram -> eig/rank -> basis+projection (svdq_compress with the fused bit): every workgroup
+// (one wavefront) takes ONE item from a host-built queue through an atomic ticket.  The queue
+// lists every unit twice -- as a Gram item, and, a configurable number of bytes later, as a
+// basis-projection item -- so that pass 2 of a tensor runs while the tensor is still (partly) in the
+// 256 MiB Infinity Cache and the small per-parameter stages cost no launches:
+//   Gram item      : gram_unit, then arrive on the unit's chunk counter; the last arriver of a chunk sums
+//                    the chunk (chunk_sum order = k_reduce's) and arrives on the parameter counter; the last
+//                    arriver of a parameter runs eig_param on its own LDS and raises ready[p].
+//   projection item: waits for ready[p] (bounded spin), then bp_unit.
+// A projection item is queued after ALL Gram items of its parameter and items are fetched in queue
+// order, so whoever a waiter depends on is already running and never waits itself: no deadlock,
+// whatever the residency.  All cross-workgroup hand-offs are agent-scope release/acquire.
+#define SVDQ_SPIN_MAX (1 << 16)
+
+struct SvdqFusedArgs {
+    const SvdqParam *params;
+    const SvdqUnit *units;
+    const int32_t *items;  // bit 31: 0 = Gram item, 1 = projection item; low bits: unit index
+    const float *const *ptrs;
+    const int64_t *rows_dev;
+    double *gram_part, *gram_part2;
+    float *Wtab;
+    double *c0;
+    float *sigma;
+    int32_t *k, *r;
+    float *energy;
+    int64_t *rows_out;
+    uint8_t *basis;
+    float *mean;
+    double *cpart;
+    int32_t *ctl;  // [0] queue head, [1] error flag, [4..) chunk counters, parameter counters, ready flags
+    int32_t n_items, n_params, NT, center, pack, max_rank;
+    float thr;
+};
+
+__device__ __forceinline__ int wave_fetch_add(int32_t *ctr, int lane) {
+    int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(t);
+}
+
+template <int NTP>
+__device__ __forceinline__ void fused_gram(float *X, int uidx, const SvdqFusedArgs &a) {
+    gram_unit<NTP>(X, uidx, a.params, a.units, a.ptrs, a.rows_dev, a.NT, a.center, a.gram_part);
+}
+
+template <int NTP, bool OUT16>
+__device__ __forceinline__ void fused_bp(float *X, typename OutT<OUT16>::type *OUT, int uidx, const SvdqFusedArgs &a) {
+    bp_unit<NTP, OUT16>(X, OUT, uidx, a.params, a.units, a.ptrs, a.rows_dev, a.NT, a.center, a.Wtab, a.k, a.r, a.basis,
+                        a.mean, a.cpart);
+}
+
+template <int NTP>
+__device__ __forceinline__ void fused_eig(float *X, int p, int lane, int64_t D, const SvdqFusedArgs &a) {
+    eig_param<64, NTP>(reinterpret_cast<double *>(X), p, lane, D, a.ptrs, a.NT, a.center, a.thr, a.max_rank,
+                       a.gram_part2, a.Wtab, a.c0, a.sigma, a.k, a.r, a.energy, a.rows_out);
+}
+
+template <int NTP, bool OUT16>
+__global__ __launch_bounds__(64) void k_fused(const SvdqFusedArgs a) {
+    using out_t = typename OutT<OUT16>::type;
+    __shared__ __attribute__((aligned(16))) float X[NTP * XS];
+    __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];
+    static_assert(sizeof(float) * NTP * XS >= SVDQ_EIG_LDS_BYTES(NTP), "eigen-stage scratch must fit in the strip");
+    const int lane = threadIdx.x & 63;
+    int32_t *chunk_arrive = a.ctl + 4;
+    int32_t *param_arrive = chunk_arrive + (size_t)a.n_params * SVDQ_RC;
+    int32_t *ready = param_arrive + a.n_params;
+    const int nn = a.NT * a.NT;
+    {
+        // the ticket, not blockIdx, orders the items: a workgroup that holds ticket i is running, so everything
+        // a waiter depends on (smaller tickets) is running too, whatever order the hardware dispatches in
+        const int it = wave_fetch_add(a.ctl, lane);
+        if (it >= a.n_items) return;
+        const int32_t code = a.items[it];
+        const int uidx = code & 0x7fffffff;
+        const int p = a.units[uidx].param;
+        if (code >= 0) {
+            fused_gram<NTP>(X, uidx, a);
+            const SvdqParam pd = a.params[p];
+            const int per = (pd.unit_count + SVDQ_RC - 1) / SVDQ_RC;
+            const int c = (uidx - pd.unit_begin) / per;
+            const int ua = c * per;
+            const int ub = ua + per < pd.unit_count ? ua + per : pd.unit_count;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this unit's partial(s) are visible ...
+            if (wave_fetch_add(&chunk_arrive[(size_t)p * SVDQ_RC + c], lane) == ub - ua - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... to the chunk's last arriver
+                const int sa = (pd.unit_begin + ua) * a.pack, sb = (pd.unit_begin + ub) * a.pack;
+                for (int e = lane; e < nn; e += 64)
+                    a.gram_part2[((size_t)p * SVDQ_RC + c) * nn + e] = chunk_sum(a.gram_part, sa, sb, nn, e);
+                const int nc = (pd.unit_count + per - 1) / per;  // non-empty chunks
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (wave_fetch_add(&param_arrive[p], lane) == nc - 1) {
+                    for (int c2 = nc; c2 < SVDQ_RC; ++c2)  // k_reduce writes zeros for empty chunks
+                        for (int e = lane; e < nn; e += 64) a.gram_part2[((size_t)p * SVDQ_RC + c2) * nn + e] = 0.0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const int64_t D = a.rows_dev ? a.rows_dev[p] : pd.rows;
+                    wave_sync();
+                    fused_eig<NTP>(X, p, lane, D, a);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // W, k, r, c0 visible before the flag
+                    if (lane == 0) __hip_atomic_store(&ready[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        } else {
+            int ok = 0;
+            for (int spin = 0; spin < SVDQ_SPIN_MAX; ++spin) {
+                int v = 0;
+                if (lane == 0) v = __hip_atomic_load(&ready[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = __builtin_amdgcn_readfirstlane(v);
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(20);
+            }
+            if (!ok) {  // cannot happen with a queue built by svdq_plan_create; never hang the GPU on a bug
+                if (lane == 0) __hip_atomic_store(&a.ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            fused_bp<NTP, OUT16>(X, OUT, uidx, a);
+        }
+    }
+}
+
+template <int NTP>
+static int launch_fused_t(const svdq_plan *pl, const SvdqFusedArgs &args, hipStream_t st) {
+    if (pl->cfg.fp16)
+        hipLaunchKernelGGL((k_fused<NTP, true>), dim3(args.n_items), dim3(64), 0, st, args);
+    else
+        hipLaunchKernelGGL((k_fused<NTP, false>), dim3(args.n_items), dim3(64), 0, st, args);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+int svdq_launch_fused(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
+                      double *gram_part2, float *W, double *c0, uint8_t *small, uint8_t *basis, float *mean,
+                      double *cpart, hipStream_t st) {
+    const svdq_small_layout &L = pl->small;
+    SvdqFusedArgs a;
+    a.params = pl->d_params;
+    a.units = pl->d_units;
+    a.items = pl->d_items;
+    a.ptrs = reinterpret_cast<const float *const *>(ptrs);
+    a.rows_dev = rows_dev;
+    a.gram_part = gram_part;
+    a.gram_part2 = gram_part2;
+    a.Wtab = W;
+    a.c0 = c0;
+    a.sigma = reinterpret_cast<float *>(small + L.sigma_off);
+    a.k = reinterpret_cast<int32_t *>(small + L.k_off);
+    a.r = reinterpret_cast<int32_t *>(small + L.r_off);
+    a.energy = reinterpret_cast<float *>(small + L.energy_off);
+    a.rows_out = reinterpret_cast<int64_t *>(small + L.rows_off);
+    a.basis = basis;
+    a.mean = mean;
+    a.cpart = cpart;
+    a.ctl = pl->d_ctl;
+    a.n_items = pl->n_items;
+    a.n_params = pl->n_params;
+    a.NT = pl->n_tasks;
+    a.center = pl->cfg.center;
+    a.pack = pl->pack;
+    a.max_rank = pl->cfg.max_rank;
+    a.thr = pl->cfg.energy_threshold;
+    switch (pl->ntp) {
+        case 4: return launch_fused_t<4>(pl, a, st);
+        case 8: return launch_fused_t<8>(pl, a, st);
+        case 12: return launch_fused_t<12>(pl, a, st);
+        case 16: return launch_fused_t<16>(pl, a, st);
+        case 20: return launch_fused_t<20>(pl, a, st);
+        case 24: return launch_fused_t<24>(pl, a, st);
+        case 28: return launch_fused_t<28>(pl, a, st);
+        case 32: return launch_fused_t<32>(pl, a, st);
+    }
+    svdq_set_error("unsupported padded task count %d", pl->ntp);
+    return SVDQ_EUNSUPPORTED;
 }
 
 // ------------------------------------------------------------------------------------ launchers

@@ -144,3 +144,68 @@ def compute_all_diagnostics(task_vectors: Dict[str, Dict[str, torch.Tensor]], co
         "average_compression_ratio": float(np.mean(ratios)) if ratios else 0,
     }
     return out
+
+
+def compute_compression_statistics(task_vectors: Dict[str, Dict[str, torch.Tensor]], compressed_all: Dict[str, Dict],
+                                   bases: Dict[str, Dict], config) -> Dict:
+    """Reference diagnostics.py:385-566: byte accounting of the compressed representation (host arithmetic).
+    Same keys; fp32 originals at 4 B/element, fp16 coefficients and bases at 2 B, RTVQ stages at
+    ceil(n * bits / 8) + 8 B of scale/zero-point."""
+    import math
+    bits, stages = config.svd_low_bits, config.svd_rtvq_stages
+    orig_task = {t: sum(d.numel() * 4 for d in tv.values()) for t, tv in task_vectors.items()}
+    first = task_vectors[next(iter(task_vectors))]
+    orig_param = {n: sum(tv[n].numel() * 4 for tv in task_vectors.values() if n in tv) for n in first.keys()}
+    tot = {"fp16": 0, "rtvq": 0, "bases": 0}
+    per_param, comp_param = {}, {}
+    for name, basis in bases.items():
+        if name not in compressed_all:
+            continue
+        ps = {"original_bytes": orig_param.get(name, 0), "compressed_bytes": 0, "fp16_high_energy_bytes": 0,
+              "rtvq_low_energy_bytes": 0, "svd_bases_bytes": 0, "k": 0, "D": 0, "compression_ratio": 0}
+        bm = basis.get("masked")
+        if bm is not None:
+            ps["k"], ps["D"] = bm.get("k", 0), bm.get("D", 0)
+            ps["svd_bases_bytes"] = (bm["U_high"].numel() + bm["U_low"].numel()) * 2
+            tot["bases"] += ps["svd_bases_bytes"]
+            for art in compressed_all[name].values():
+                if art is None or art.get("masked") is None:
+                    continue
+                ma = art["masked"]
+                b16 = ma["c_high_fp16"].numel() * 2
+                bq = sum(math.ceil(p["quantized"].numel() * bits / 8) + 8 for p in ma["c_low_quant"].get("payloads", []))
+                ps["fp16_high_energy_bytes"] += b16
+                ps["rtvq_low_energy_bytes"] += bq
+                tot["fp16"] += b16
+                tot["rtvq"] += bq
+        ps["compressed_bytes"] = ps["fp16_high_energy_bytes"] + ps["rtvq_low_energy_bytes"] + ps["svd_bases_bytes"]
+        if ps["original_bytes"] > 0:
+            ps["compression_ratio"] = ps["original_bytes"] / max(ps["compressed_bytes"], 1)
+        per_param[name] = ps
+        comp_param[name] = ps["compressed_bytes"]
+    o_tot, c_tot = sum(orig_task.values()), tot["fp16"] + tot["rtvq"] + tot["bases"]
+    return {
+        "original": {"total_bytes": o_tot, "per_task_bytes": orig_task, "per_param_bytes": orig_param},
+        "compressed": {"total_bytes": c_tot, "fp16_high_energy_bytes": tot["fp16"], "rtvq_low_energy_bytes": tot["rtvq"],
+                       "svd_bases_bytes": tot["bases"], "per_task_bytes": {}, "per_param_bytes": comp_param},
+        "per_parameter": per_param,
+        "summary": {"original_size_mb": o_tot / (1024 * 1024), "compressed_size_mb": c_tot / (1024 * 1024),
+                    "overall_compression_ratio": o_tot / max(c_tot, 1), "fp16_fraction": tot["fp16"] / max(c_tot, 1),
+                    "rtvq_fraction": tot["rtvq"] / max(c_tot, 1), "bases_fraction": tot["bases"] / max(c_tot, 1),
+                    "num_parameters": len(per_param), "num_tasks": len(task_vectors), "num_bits": bits,
+                    "num_stages": stages}}
+
+
+def print_detailed_compression_report(stats: Dict, config=None) -> None:
+    """Short form of diagnostics.py:569-708 (the numbers, not the tutorial text)."""
+    s = stats["summary"]
+    print(f"   compression: {s['original_size_mb']:.2f} MB -> {s['compressed_size_mb']:.2f} MB "
+          f"({s['overall_compression_ratio']:.2f}x; bases {100 * s['bases_fraction']:.1f} %, fp16 "
+          f"{100 * s['fp16_fraction']:.1f} %, RTVQ {100 * s['rtvq_fraction']:.1f} %)")
+
+
+def print_diagnostics_summary(diagnostics: Dict) -> None:
+    """Short form of diagnostics.py:711-."""
+    s = diagnostics.get("summary", {})
+    print(f"   reconstruction: average relative error {s.get('average_reconstruction_error', 0):.6f} over "
+          f"{s.get('num_parameters', len(diagnostics.get('per_parameter', {})))} parameters")

@@ -6,6 +6,8 @@ Mask operators on the GPU with the reference's names and semantics
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import torch
@@ -197,93 +199,6 @@ def combine_masks(task_masks: Dict[str, Dict[str, torch.Tensor]], strategy: str 
     return combined
 
 
-def compact(self, masks, srcs_per_param, want_false: bool):
-        """masks[q]: combined mask; srcs_per_param[q]: list of n_src fp32 tensors of that shape.
-        Returns (dst_true[q][s], dst_false[q][s] | None, count_true [Q], count_false [Q] | None);
-        destination buffers are sized for the worst case, counts stay on the device."""
-        n_src = len(srcs_per_param[0])
-        mb = [_as_mask_bytes(m, self.device) for m in masks]
-        srcs = [[prepare_vector(v, self.device) for v in vs] for vs in srcs_per_param]
-        for q in range(self.Q):
-            if mb[q].numel() != self.numels[q] or len(srcs[q]) != n_src or any(v.numel() != self.numels[q] for v in srcs[q]):
-                raise ValueError(f"Shape mismatch: tensor vs mask for parameter {q}")
-        dt = [[torch.empty(self.numels[q], dtype=torch.float32, device=self.device) for _ in range(n_src)]
-              for q in range(self.Q)]
-        df = [[torch.empty(self.numels[q], dtype=torch.float32, device=self.device) for _ in range(n_src)]
-              for q in range(self.Q)] if want_false else None
-        ct = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
-        cf = torch.zeros(self.Q, dtype=torch.int64, device=self.device) if want_false else None
-        mt = self._table(mb)
-        st = self._table([v for vs in srcs for v in vs])
-        tt = self._table([v for vs in dt for v in vs])
-        ft = self._table([v for vs in df for v in vs]) if want_false else None
-        with torch.cuda.device(self.device):
-            nat.check(self.lib.svdq_maskset_compact(self._h, _ptr(mt), _ptr(st), _ptr(tt), _ptr(ft), n_src, _ptr(ct),
-                                                    _ptr(cf), _ptr(self.work), _stream_ptr()), "svdq_maskset_compact")
-        self._keep_x = (mb, srcs, mt, st, tt, ft)
-        return dt, df, ct, cf
-
-
-def _combine(masks: List[torch.Tensor], strategy: str) -> torch.Tensor:
-    if not masks:
-        raise ValueError("Empty mask list")
-    if strategy not in nat.MASK_STRATEGIES:
-        raise ValueError(f"Unknown mask strategy: {strategy}")
-    shape = masks[0].shape
-    for m in masks[1:]:
-        if m.shape != shape:
-            raise ValueError(f"Shape mismatch: mask {m.shape} vs mask {shape}")
-    out_dev = masks[0].device
-    dev = resolve_device(out_dev if masks[0].is_cuda else "cuda")
-    flat = [_as_mask_bytes(m, dev) for m in masks]
-    numel = flat[0].numel()
-    if numel == 0:
-        return torch.zeros(shape, dtype=torch.bool, device=out_dev)
-    lib = nat.lib()
-    table = torch.tensor([f.data_ptr() for f in flat], dtype=torch.int64).to(dev)
-    out = torch.empty(numel, dtype=torch.uint8, device=dev)
-    count = torch.zeros(1, dtype=torch.int64, device=dev)
-    work = torch.empty(int(lib.svdq_mask_work_bytes(numel)), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        nat.check(lib.svdq_mask_combine(_ptr(table), len(flat), numel, nat.MASK_STRATEGIES[strategy], _ptr(out),
-                                        _ptr(count), _ptr(work), _stream_ptr()), "svdq_mask_combine")
-    return out.view(torch.bool).view(shape).to(out_dev)
-
-
-def compute_union_mask(masks: List[torch.Tensor]) -> torch.Tensor:
-    return _combine(masks, "union")
-
-
-def compute_intersection_mask(masks: List[torch.Tensor]) -> torch.Tensor:
-    return _combine(masks, "intersection")
-
-
-def compute_majority_mask(masks: List[torch.Tensor], threshold: float = 0.5) -> torch.Tensor:
-    if threshold != 0.5:
-        raise ValueError("only the reference's default threshold 0.5 is implemented on the HIP path")
-    return _combine(masks, "majority")
-
-
-def combine_masks(task_masks: Dict[str, Dict[str, torch.Tensor]], strategy: str = "union", device: str = "cpu",
-                  verbose: bool = True) -> Dict[str, torch.Tensor]:
-    """Reference mask_loader.py:488-648: per parameter, combine the masks of the tasks that have it."""
-    if not task_masks:
-        return {}
-    names = set()
-    for pm in task_masks.values():
-        if pm is not None:
-            names.update(pm.keys())
-    combined = {}
-    for name in names:
-        lst = [pm[name].to(device) for pm in task_masks.values() if pm is not None and name in pm]
-        if not lst:
-            continue
-        if strategy not in nat.MASK_STRATEGIES:
-            raise ValueError(f"Unknown mask strategy: {strategy}")
-        combined[name] = _combine(lst, strategy)
-    return combined
-
-
 def compact(vectors: List[torch.Tensor], mask: torch.Tensor, invert: bool = False):
     """Order-preserving compaction of several same-shape fp32 tensors under one mask, on device.
     Returns (flat device tensors sized for the worst case, device int64 count[1], keep-alive)."""
@@ -358,3 +273,95 @@ def reconstruct_from_masked(masked_values: torch.Tensor, unmasked_values: Option
         nat.check(lib.svdq_mask_expand(_ptr(sig), _ptr(noi), _ptr(mb), numel, _ptr(out), _ptr(work), _stream_ptr()),
                   "svdq_mask_expand")
     return out.view(original_shape).to(out_dev)
+
+
+# ------------------------------------------------------------------------------- mask files (host plumbing)
+def state_dict_to_vector(state_dict: Dict[str, torch.Tensor], remove_keys: Optional[List[str]] = None) -> torch.Tensor:
+    """Reference mask_loader.py:66-105: flattened tensors concatenated in sorted-key order."""
+    skip = set(remove_keys or [])
+    flat = [state_dict[k].flatten() for k in sorted(state_dict.keys()) if k not in skip]
+    return torch.cat(flat) if flat else torch.tensor([])
+
+
+def vector_to_state_dict(vector: torch.Tensor, reference_state_dict: Dict[str, torch.Tensor],
+                         remove_keys: Optional[List[str]] = None) -> Dict[str, torch.Tensor]:
+    """Inverse of state_dict_to_vector (what mask_loader.py:108-122 intends: its body references an
+    undefined name and cannot run as written)."""
+    skip = set(remove_keys or [])
+    out, pos = {}, 0
+    for k in sorted(reference_state_dict.keys()):
+        if k in skip:
+            continue
+        n = reference_state_dict[k].numel()
+        out[k] = vector[pos:pos + n].view(reference_state_dict[k].shape)
+        pos += n
+    return out
+
+
+def load_tall_mask_file(mask_path: str, reference_state_dict: Dict[str, torch.Tensor],
+                        remove_keys: Optional[List[str]] = None, device: str = "cpu") -> Dict[str, Dict[str, torch.Tensor]]:
+    """Reference mask_loader.py:125-206: {task: bit-packed mask over the flattened state dict} -> per-parameter
+    bool masks.  The file is read with loaders that execute nothing: ``numpy.load`` (an ``.npz`` with one packed
+    array per task) or ``torch.load(weights_only=True)`` (a dict of uint8 tensors).  The reference's own files are
+    pickled dicts of numpy arrays read with ``weights_only=False``; convert those once with
+    ``numpy.savez(path, **packed)``."""
+    import numpy as np
+    if not os.path.exists(mask_path):
+        raise FileNotFoundError(f"TALL mask file not found: {mask_path}")
+    packed = None
+    try:
+        z = np.load(mask_path, allow_pickle=False)
+        if hasattr(z, "files"):
+            packed = {k: z[k] for k in z.files}
+    except Exception:
+        packed = None
+    if packed is None:
+        try:
+            packed = torch.load(mask_path, map_location="cpu", weights_only=True)
+        except Exception as e:
+            raise RuntimeError(f"{mask_path}: not loadable without unpickling arbitrary objects ({e}); "
+                               "convert it with numpy.savez(path, **packed_masks)") from e
+    skip = set(remove_keys or [])
+    expected = sum(v.numel() for k, v in reference_state_dict.items() if k not in skip)
+    out = {}
+    for task, pm in packed.items():
+        arr = pm.cpu().numpy() if isinstance(pm, torch.Tensor) else np.asarray(pm)
+        if arr.dtype != np.uint8:
+            raise TypeError(f"Unexpected type for packed_mask: {arr.dtype}")
+        bits = torch.from_numpy(np.unpackbits(arr)[:expected].copy()).to(device)
+        out[task] = {k: v.bool() for k, v in vector_to_state_dict(bits, reference_state_dict, remove_keys).items()}
+    return out
+
+
+def load_single_mask(mask_path: str, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """Reference mask_loader.py:209-239 (safe loader)."""
+    if not os.path.exists(mask_path):
+        raise FileNotFoundError(f"Mask file not found: {mask_path}")
+    masks = torch.load(mask_path, map_location=device, weights_only=True)
+    return {k: (m if m.dtype == torch.bool else m.bool()) for k, m in masks.items()}
+
+
+def load_task_masks(mask_dir: str, task_names: List[str], device: str = "cpu",
+                    reference_state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                    remove_keys: Optional[List[str]] = None, verbose: bool = True) -> Dict[str, Optional[Dict]]:
+    """Reference mask_loader.py:242-409: a TALL_mask_{N}task(s) file if present (and a reference state dict is
+    given), else one ``{task}_mask.pt`` / ``{task}.pt`` / ``{task}/mask.pt`` per task; missing -> None."""
+    n = len(task_names)
+    if reference_state_dict is not None:
+        for stem in (f"TALL_mask_{n}task", f"TALL_mask_{n}tasks", f"tall_mask_{n}task", f"tall_mask_{n}tasks"):
+            for ext in (".npy", ".npz", ".pt"):
+                path = os.path.join(mask_dir, stem + ext)
+                if os.path.exists(path):
+                    allm = load_tall_mask_file(path, reference_state_dict, remove_keys=remove_keys, device=device)
+                    return {t: allm.get(t) for t in task_names}
+    out: Dict[str, Optional[Dict]] = {}
+    for t in task_names:
+        out[t] = None
+        for cand in (f"{t}_mask.pt", f"{t}.pt", os.path.join(t, "mask.pt")):
+            path = os.path.join(mask_dir, cand)
+            if os.path.exists(path):
+                out[t] = load_single_mask(path, device)
+                break
+        if verbose and out[t] is None:
+            print(f"   no mask file for task {t}")
+    return out

@@ -635,6 +635,8 @@ def gen_cluster():
     massign = {"T0": 0, "T1": 0, "T2": 1, "T3": 1, "T4": 1, "T5": 2}
     merged = ref_merge.merge_with_clustering(compressed, bases, masks, weights, massign, original_shapes, cfg,
                                              device="cpu")
+    cstats = ref_diag.compute_compression_statistics(mtv, compressed, bases, cfg)
+    out["compression_stats_json"] = np.array(json.dumps(cstats, sort_keys=True))
     out["mwc__assign"] = np.array([massign[t] for t in mtasks], dtype=np.int64)
     for pname in mshapes:
         assert torch.isfinite(merged[pname]).all()

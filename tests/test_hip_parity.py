@@ -395,6 +395,41 @@ def test_pipelined_schedule_and_ranges_bit_identical(sq, orc):
     same_artifacts(rng)
 
 
+@pytest.mark.parametrize("N,fp16,lag_mb", [(8, True, 1), (8, True, 0), (3, False, 2), (16, True, 4), (20, True, 1)])
+def test_fused_schedule_bit_identical(sq, orc, N, fp16, lag_mb):
+    """svdq_compress with the fused bit (one launch for gram + eig + basis_project: atomic item queue, last-arriver
+    reduction and eigen-stage, in-memory ready flags) produces exactly the artifacts of the four plain launches,
+    with and without device-side row counts, run after run."""
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    sizes = [300000, 768, 70001, 1024 * 96, 5000, 262144, 40, 1024 * 520 + 7]
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 190 + i)] for i, D in enumerate(sizes)]
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=fp16, low_bits=4, rtvq_stages=2, device=dev,
+              unit_rows=1024)
+    rows_dev = torch.tensor([s - (s // 7) for s in sizes], dtype=torch.int64, device=dev)   # masked-style counts
+    for rd in (None, rows_dev):
+        ref = CompressPlan(sizes, N, **kw)
+        ref.run(ref.pointer_table(vecs), rd)
+        fus = CompressPlan(sizes, N, flags=4 | (lag_mb << 8), **kw)
+        tab = fus.pointer_table(vecs)
+        fus.run(tab, rd)
+        torch.cuda.synchronize()
+        sm = ref.fetch_small()
+        sf = fus.fetch_small()                      # raises if the schedule reported a timeout
+        assert torch.equal(fus.small, ref.small)
+        for p in range(len(sizes)):
+            rows = int(sm.rows[p])
+            a = ref.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), rows)
+            b = fus.basis_tensors(p, int(sf.k[p]), int(sf.r[p]), rows)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            assert (a[2] is None and b[2] is None) or torch.equal(a[2], b[2])
+        first = fus.small.clone()
+        for _ in range(3):                          # the control block is reset by every call
+            fus.run(tab, rd)
+        torch.cuda.synchronize()
+        assert torch.equal(fus.small, first)
+
+
 # ------------------------------------------------------------------------------- masks
 def test_masks_vs_reference_vectors(sq):
     g = load_golden("masks.npz")
