@@ -60,8 +60,10 @@ def parse():
                          "gram(g+1) | eig(g) on a side stream | basis_project(g) so a group's deltas are still "
                          "in the Infinity Cache for its second pass (0 = four whole-model launches)")
     ap.add_argument("--masks", choices=("none", "union", "intersection", "majority"), default="none",
-                    help="BASELINE configs[2]: per-task tall masks (rand > 0.7) combined on device, then every "
-                         "parameter compacted under its combined mask before the four stages")
+                    help="BASELINE configs[2]: per-task tall masks (rand > 0.7) combined on device; the four stages "
+                         "then read every task tensor through the combined mask's index list (gather mode)")
+    ap.add_argument("--masks-compact", action="store_true",
+                    help="A/B: materialise compacted copies of the deltas (the pre-gather schedule) instead")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -186,8 +188,12 @@ def main():
         per_task = [[torch.rand(r, device=dev, generator=gm) > 0.7 for _ in range(N)] for r in rows]
         mset = MaskSet(rows, dev)
         comb, counts = mset.prepare_combine(per_task, args.masks)
-        dt, _, ct, _ = mset.prepare_compact([c.view(torch.bool) for c in comb], views, want_false=False)
-        table = plan.pointer_table(dt)
+        if args.masks_compact:
+            dt, _, ct, _ = mset.prepare_compact([c.view(torch.bool) for c in comb], views, want_false=False)
+            table = plan.pointer_table(dt)
+        else:
+            it, _, ct, _ = mset.prepare_indices([c.view(torch.bool) for c in comb], want_false=False)
+            itab = torch.tensor([x.data_ptr() for x in it], dtype=torch.int64).to(dev)
         rows_dev = ct
     torch.cuda.synchronize()
 
@@ -234,9 +240,13 @@ def main():
 
     def step(events=None):
         if mset is not None:
-            mset.run_combine()
-            mset.run_compact()
-            plan.run(table, rows_dev)
+            if args.masks_compact:
+                mset.run_combine()
+                mset.run_compact()
+                plan.run(table, rows_dev)
+            else:
+                mset.run_combine_indices()
+                plan.run_gather(table, itab, rows_dev)
             if world > 1:
                 shard.gather_small(plan.small.cpu() if on_cpu else plan.small)
             return

@@ -164,6 +164,16 @@ int svdq_coeff_quantize_range(const svdq_plan *plan, void *workspace_dev, void *
 int svdq_task_gram(const svdq_plan *plan, const void *delta_ptrs, const int64_t *rows_dev, void *workspace,
                    double *out_gram, void *stream);
 
+/* svdq_compress for MASKED parameters without a compaction pass (replaces the 2*N boolean-index gathers per
+ * parameter of cli.py:333 / compress.py:144, i.e. apply_mask_to_tensor mask_loader.py:651-679 feeding
+ * construct_masked_basis and compress_masked_regions): delta_ptrs name the original full-size tensors,
+ * index_ptrs is a device table [n_params] of int32 lists -- the ascending flat positions of the selected
+ * elements of each parameter (svdq_maskset_indices) -- and rows_dev[p] their number (<= the plan's rows[p]).
+ * Artifacts are those of svdq_compress on the compacted tensors, bit for bit. */
+int svdq_compress_gather(const svdq_plan *plan, const void *delta_ptrs, const void *index_ptrs,
+                         const int64_t *rows_dev, void *workspace_dev, void *small_dev, void *basis_dev,
+                         float *mean_dev, void *stream);
+
 /* ---- the step before the path: task-vector ingest and whole-tensor quantization ("TVQ"),
  * batched over a plan's parameters x tasks.  All pointer tables are DEVICE arrays of device addresses,
  * parameter-major ([p * n_tasks + t]); fp32 buffers 16-byte aligned, code buffers 4-byte aligned. ---- */
@@ -249,6 +259,23 @@ int     svdq_maskset_combine(const svdq_maskset *ms, const void *mask_ptrs_dev, 
 int     svdq_maskset_compact(const svdq_maskset *ms, const void *mask_ptrs_dev, const void *src_ptrs_dev,
                              const void *dst_true_ptrs_dev, const void *dst_false_ptrs_dev, int32_t n_src,
                              int64_t *count_true_dev, int64_t *count_false_dev, void *work_dev, void *stream);
+
+/* Index lists instead of compacted copies: idx_true_ptrs[q] (int32, room for numel[q] entries, 16-byte aligned)
+ * receives the ascending flat positions of the set elements of mask q, idx_false_ptrs[q] (NULL table = skip)
+ * those of the cleared ones; counts as in svdq_maskset_compact.  This is what `flat[mask]` / `flat[~mask]`
+ * (mask_loader.py:651-709) select; svdq_compress_gather reads the task deltas through these lists, so the
+ * 2*N compacted copies per parameter never exist. */
+int     svdq_maskset_indices(const svdq_maskset *ms, const void *mask_ptrs_dev, const void *idx_true_ptrs_dev,
+                             const void *idx_false_ptrs_dev, int64_t *count_true_dev, int64_t *count_false_dev,
+                             void *work_dev, void *stream);
+
+/* svdq_maskset_combine followed by svdq_maskset_indices on the combined masks in 3 launches: the combine pass
+ * already counts every tile, so the separate counting pass over the combined masks is skipped.
+ * (combine_masks mask_loader.py:488-648 feeding the flat[mask] selections of cli.py:333 / compress.py:144.) */
+int     svdq_maskset_combine_indices(const svdq_maskset *ms, const void *mask_ptrs_dev, int32_t n_masks,
+                                     int32_t strategy, const void *out_ptrs_dev, const void *idx_true_ptrs_dev,
+                                     const void *idx_false_ptrs_dev, int64_t *count_true_dev,
+                                     int64_t *count_false_dev, void *work_dev, void *stream);
 
 /* ---- merge consumers (the parity reconstruction of R14)
  *      svdq_reconstruct: reconstruct_from_coefficients (merge.py:144-194):

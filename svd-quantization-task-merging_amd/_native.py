@@ -78,6 +78,11 @@ SIGNATURES = {
     "svdq_maskset_combine": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "svdq_maskset_compact": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
+    "svdq_maskset_indices": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_maskset_combine_indices": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_compress_gather": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
     "svdq_project": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
     "svdq_project_work_bytes": (c_int64, [c_int64, c_int32]),

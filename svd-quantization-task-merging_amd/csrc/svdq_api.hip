@@ -328,8 +328,8 @@ static void unit_range(const svdq_plan *pl, int32_t param0, int32_t nparams, int
     *nu = b.unit_begin + b.unit_count - a.unit_begin;
 }
 
-extern "C" int svdq_gram_center_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
-                                      int32_t param0, int32_t nparams, void *stream) {
+static int gram_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, int32_t param0,
+                      int32_t nparams, const void *idx, void *stream) {
     if (!pl || !ptrs || !workspace) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
@@ -338,7 +338,12 @@ extern "C" int svdq_gram_center_range(const svdq_plan *pl, const void *ptrs, con
     int u0, nu;
     unit_range(pl, param0, nparams, &u0, &nu);
     return svdq_launch_gram(pl, ptrs, rows_dev, reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off)), u0, nu,
-                            pl->cfg.center, (hipStream_t)stream);
+                            pl->cfg.center, idx, (hipStream_t)stream);
+}
+
+extern "C" int svdq_gram_center_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
+                                      int32_t param0, int32_t nparams, void *stream) {
+    return gram_range(pl, ptrs, rows_dev, workspace, param0, nparams, nullptr, stream);
 }
 
 extern "C" int svdq_task_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
@@ -350,14 +355,13 @@ extern "C" int svdq_task_gram(const svdq_plan *pl, const void *ptrs, const int64
     hipStream_t st = (hipStream_t)stream;
     double *part = reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off));
     double *part2 = reinterpret_cast<double *>(ws(workspace, pl->ws_gram2_off));
-    if (int rc = svdq_launch_gram(pl, ptrs, rows_dev, part, 0, pl->n_units, /*center=*/0, st)) return rc;
+    if (int rc = svdq_launch_gram(pl, ptrs, rows_dev, part, 0, pl->n_units, /*center=*/0, nullptr, st)) return rc;
     if (int rc = svdq_launch_reduce(pl, part, part2, 0, pl->n_params, st)) return rc;
     return svdq_launch_gram_total(pl, part2, out_gram, st);
 }
 
-extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
-                                          void *workspace, void *small, int32_t param0, int32_t nparams,
-                                          void *stream) {
+static int eig_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, void *small,
+                     int32_t param0, int32_t nparams, const void *idx, void *stream) {
     if (!pl || !ptrs || !workspace || !small) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
@@ -370,12 +374,17 @@ extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs,
     return svdq_launch_eig(pl, ptrs, rows_dev, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram2_off)),
                            reinterpret_cast<float *>(ws(workspace, pl->ws_w_off)),
                            reinterpret_cast<double *>(ws(workspace, pl->ws_c0_off)), reinterpret_cast<uint8_t *>(small),
-                           param0, nparams, (hipStream_t)stream);
+                           param0, nparams, idx, (hipStream_t)stream);
 }
 
-extern "C" int svdq_basis_project_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
-                                        void *workspace, const void *small, void *basis, float *mean, int32_t param0,
-                                        int32_t nparams, void *stream) {
+extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
+                                          void *workspace, void *small, int32_t param0, int32_t nparams,
+                                          void *stream) {
+    return eig_range(pl, ptrs, rows_dev, workspace, small, param0, nparams, nullptr, stream);
+}
+
+static int bp_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, const void *small,
+                    void *basis, float *mean, int32_t param0, int32_t nparams, const void *idx, void *stream) {
     if (!pl || !ptrs || !workspace || !small || !basis) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
@@ -393,7 +402,13 @@ extern "C" int svdq_basis_project_range(const svdq_plan *pl, const void *ptrs, c
                                      reinterpret_cast<const int32_t *>(sm + pl->small.r_off),
                                      reinterpret_cast<uint8_t *>(basis), mean,
                                      reinterpret_cast<double *>(ws(workspace, pl->ws_cpart_off)), u0, nu,
-                                     pl->cfg.reserved & 1, (hipStream_t)stream);
+                                     pl->cfg.reserved & 1, idx, (hipStream_t)stream);
+}
+
+extern "C" int svdq_basis_project_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
+                                        void *workspace, const void *small, void *basis, float *mean, int32_t param0,
+                                        int32_t nparams, void *stream) {
+    return bp_range(pl, ptrs, rows_dev, workspace, small, basis, mean, param0, nparams, nullptr, stream);
 }
 
 extern "C" int svdq_coeff_quantize_range(const svdq_plan *pl, void *workspace, void *small, int32_t param0,
@@ -502,6 +517,28 @@ extern "C" int svdq_compress(const svdq_plan *pl, const void *ptrs, const int64_
     int rc = svdq_gram_center(pl, ptrs, rows_dev, workspace, stream);
     if (rc == SVDQ_OK) rc = svdq_eig_rank_select(pl, ptrs, rows_dev, workspace, small, stream);
     if (rc == SVDQ_OK) rc = svdq_basis_project(pl, ptrs, rows_dev, workspace, small, basis, mean, stream);
+    if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
+    return rc;
+}
+
+// Masked parameters without a compaction pass: delta_ptrs name the ORIGINAL (full-size) tensors,
+// index_ptrs[p] the ascending source positions of parameter p's selected elements (svdq_maskset_indices),
+// rows_dev[p] how many there are.  Outputs (basis rows, mean, coefficients) are those of the compacted
+// tensors, bit for bit.
+extern "C" int svdq_compress_gather(const svdq_plan *pl, const void *ptrs, const void *index_ptrs,
+                                    const int64_t *rows_dev, void *workspace, void *small, void *basis, float *mean,
+                                    void *stream) {
+    if (!pl || !index_ptrs || !rows_dev) {
+        svdq_set_error("svdq_compress_gather: plan, index_ptrs and rows_dev are required");
+        return SVDQ_EINVAL;
+    }
+    if (small)
+        HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(small) + pl->small.status_off, 0, sizeof(int32_t),
+                               (hipStream_t)stream));
+    int rc = gram_range(pl, ptrs, rows_dev, workspace, 0, pl->n_params, index_ptrs, stream);
+    if (rc == SVDQ_OK) rc = eig_range(pl, ptrs, rows_dev, workspace, small, 0, pl->n_params, index_ptrs, stream);
+    if (rc == SVDQ_OK)
+        rc = bp_range(pl, ptrs, rows_dev, workspace, small, basis, mean, 0, pl->n_params, index_ptrs, stream);
     if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
     return rc;
 }

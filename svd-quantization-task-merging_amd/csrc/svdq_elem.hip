@@ -322,6 +322,22 @@ __device__ __forceinline__ unsigned long long vote8(unsigned long long acc, int 
     return out;
 }
 
+// sum over the 256 threads of a block, valid in thread 0: wave shuffles, then one LDS hop for the 4 wave sums
+__device__ __forceinline__ unsigned block_sum_u32(unsigned v) {
+    __shared__ unsigned s_w[ELT_THREADS / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned tot = 0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < ELT_THREADS / 64; ++w) tot += s_w[w];
+    }
+    __syncthreads();
+    return tot;
+}
+
 // one 2048-element tile: combined mask out, number of selected elements returned by thread 0 via *cnt_out
 __device__ void combine_tile(const uint8_t *const *masks, int n_masks, int strategy, int64_t tile, int64_t numel,
                              uint8_t *out, unsigned *cnt_out) {
@@ -330,7 +346,13 @@ __device__ void combine_tile(const uint8_t *const *masks, int n_masks, int strat
     if (base < numel) {
         const int lim = (int)((numel - base) < 8 ? (numel - base) : 8);
         unsigned long long acc = 0;
-        for (int m = 0; m < n_masks; ++m) acc += load_mask8(masks[m] + base, lim);
+        for (int m0 = 0; m0 < n_masks; m0 += 8) {   // 8 independent loads in flight per thread
+            unsigned long long w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (m0 + j < n_masks) ? load_mask8(masks[m0 + j] + base, lim) : 0ull;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += w[j];
+        }
         const unsigned long long res = vote8(acc, n_masks, strategy);
         if (lim == 8 && (reinterpret_cast<uintptr_t>(out + base) & 7) == 0) {
             *reinterpret_cast<unsigned long long *>(out + base) = res;
@@ -339,14 +361,8 @@ __device__ void combine_tile(const uint8_t *const *masks, int n_masks, int strat
         }
         cnt = (unsigned)__popcll(lim == 8 ? res : (res & ((1ull << (8 * lim)) - 1)));
     }
-    __shared__ unsigned s_cnt[ELT_THREADS];
-    s_cnt[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *cnt_out = s_cnt[0];
+    const unsigned tot = block_sum_u32(cnt);
+    if (threadIdx.x == 0) *cnt_out = tot;
 }
 
 // one tile of an order-preserving compaction for n_src buffers: every source tile is loaded with
@@ -429,14 +445,8 @@ __global__ __launch_bounds__(ELT_THREADS) void k_mask_count(const uint8_t *__res
     unsigned cnt = 0;
     for (int e = 0; e < 8; ++e)
         if (base + e < numel) cnt += ((mask[base + e] != 0) != (invert != 0)) ? 1u : 0u;
-    __shared__ unsigned s_cnt[ELT_THREADS];
-    s_cnt[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = s_cnt[0];
+    const unsigned tot = block_sum_u32(cnt);
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
 }
 
 // exclusive scan of the tile counts (one block; ntiles <= a few thousand), total -> count_out
@@ -806,12 +816,16 @@ __global__ __launch_bounds__(ELT_THREADS) void k_maskset_combine(const int32_t *
                                                                  const int64_t *__restrict__ numel_tab,
                                                                  const uint8_t *const *__restrict__ masks, int n_masks,
                                                                  int strategy, uint8_t *const *__restrict__ outs,
-                                                                 unsigned long long *__restrict__ counts) {
+                                                                 unsigned long long *__restrict__ counts,
+                                                                 unsigned *__restrict__ tile_counts) {
     const int q = tile_param[blockIdx.x];
     __shared__ unsigned cnt;
     combine_tile(masks + (size_t)q * n_masks, n_masks, strategy, blockIdx.x - tile_begin[q], numel_tab[q], outs[q], &cnt);
     __syncthreads();
-    if (threadIdx.x == 0 && cnt) atomicAdd(&counts[q], (unsigned long long)cnt);
+    if (threadIdx.x == 0) {
+        if (tile_counts) tile_counts[blockIdx.x] = cnt;       // feeds the index build without a counting pass
+        else if (cnt) atomicAdd(&counts[q], (unsigned long long)cnt);
+    }
 }
 
 __global__ __launch_bounds__(ELT_THREADS) void k_maskset_count(const int32_t *__restrict__ tile_param,
@@ -824,16 +838,14 @@ __global__ __launch_bounds__(ELT_THREADS) void k_maskset_count(const int32_t *__
     const uint8_t *mask = masks[q];
     const int64_t base = (int64_t)(blockIdx.x - tile_begin[q]) * MASK_TILE + (int64_t)threadIdx.x * 8;
     unsigned cnt = 0;
-    for (int e = 0; e < 8; ++e)
-        if (base + e < numel) cnt += mask[base + e] != 0 ? 1u : 0u;
-    __shared__ unsigned s_cnt[ELT_THREADS];
-    s_cnt[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int off = ELT_THREADS / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off];
-        __syncthreads();
+    if (base < numel) {
+        const int lim = (int)((numel - base) < 8 ? (numel - base) : 8);
+        unsigned long long w = load_mask8(mask + base, lim);      // one 8-byte load; bytes are 0 or 1
+        w = (w | (w >> 1) | (w >> 2) | (w >> 3) | (w >> 4) | (w >> 5) | (w >> 6) | (w >> 7)) & 0x0101010101010101ull;
+        cnt = (unsigned)__popcll(w);
     }
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = s_cnt[0];
+    const unsigned tot = block_sum_u32(cnt);
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
 }
 
 // one block per parameter: exclusive scan of ITS tile counts; true / false totals out
@@ -904,7 +916,7 @@ extern "C" int svdq_maskset_combine(const svdq_maskset *ms, const void *mask_ptr
     hipLaunchKernelGGL(k_maskset_combine, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param,
                        ms->d_tile_begin, ms->d_numel, reinterpret_cast<const uint8_t *const *>(mask_ptrs), n_masks,
                        strategy, reinterpret_cast<uint8_t *const *>(out_ptrs),
-                       reinterpret_cast<unsigned long long *>(counts));
+                       reinterpret_cast<unsigned long long *>(counts), (unsigned *)nullptr);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
@@ -930,6 +942,140 @@ extern "C" int svdq_maskset_compact(const svdq_maskset *ms, const void *mask_ptr
                        ms->d_tile_begin, ms->d_numel, mp, reinterpret_cast<const float *const *>(src_ptrs),
                        reinterpret_cast<float *const *>(dst_true_ptrs),
                        reinterpret_cast<float *const *>(dst_false_ptrs), n_src, tile_offsets);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+// inclusive prefix sum over the 256 threads of a block (wave shuffles + one LDS hop); *total = block sum
+__device__ __forceinline__ unsigned block_scan_u32(unsigned v, unsigned *total) {
+    __shared__ unsigned s_w[ELT_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    if (lane == 63) s_w[w] = v;
+    __syncthreads();
+    unsigned add = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < ELT_THREADS / 64; ++i) {
+        if (i < w) add += s_w[i];
+        tot += s_w[i];
+    }
+    __syncthreads();
+    *total = tot;
+    return v + add;
+}
+
+// Index lists for the gather mode of the streaming passes (svdq_compress_gather): the ascending flat positions
+// of the selected (and, when asked, of the unselected) elements of every parameter.  Same tile scan as the
+// compaction; 4 B written per element instead of 4 N B read + 4 N B written.
+__global__ __launch_bounds__(ELT_THREADS) void k_maskset_index(const int32_t *__restrict__ tile_param,
+                                                               const int32_t *__restrict__ tile_begin,
+                                                               const int64_t *__restrict__ numel_tab,
+                                                               const uint8_t *const *__restrict__ masks,
+                                                               int32_t *const *__restrict__ idx_true,
+                                                               int32_t *const *__restrict__ idx_false,
+                                                               const unsigned long long *__restrict__ tile_offsets) {
+    __shared__ int32_t lt[MASK_TILE], lf[MASK_TILE];
+    const int q = tile_param[blockIdx.x];
+    const int64_t tile = blockIdx.x - tile_begin[q], numel = numel_tab[q];
+    const uint8_t *mask = masks[q];
+    const int tid = threadIdx.x;
+    const int64_t tbase = tile * MASK_TILE;
+    const int64_t base = tbase + (int64_t)tid * 8;
+    const int lim = base < numel ? (int)((numel - base) < 8 ? (numel - base) : 8) : 0;
+    const unsigned long long w = lim ? load_mask8(mask + base, lim) : 0;
+    unsigned sel = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sel |= (unsigned)((w >> (8 * e)) & 1) << e;
+    const unsigned cnt = __popc(sel);
+    unsigned tot_true;
+    const unsigned incl = block_scan_u32(cnt, &tot_true);
+    const int tile_n = (int)((numel - tbase) < MASK_TILE ? (numel - tbase) : MASK_TILE);
+    const unsigned tot_false = (unsigned)tile_n - tot_true;
+    unsigned jt = incl - cnt, jf = (unsigned)(tid * 8) - jt;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (e < lim) {
+            if (sel & (1u << e))
+                lt[jt++] = (int32_t)(base + e);
+            else
+                lf[jf++] = (int32_t)(base + e);
+        }
+    }
+    __syncthreads();
+    const unsigned long long t_off = tile_offsets[blockIdx.x];
+    int32_t *dt = idx_true[q] + t_off;
+    for (unsigned i = tid; i < tot_true; i += ELT_THREADS) dt[i] = lt[i];
+    if (idx_false) {
+        int32_t *df = idx_false[q] + ((unsigned long long)tbase - t_off);
+        for (unsigned i = tid; i < tot_false; i += ELT_THREADS) df[i] = lf[i];
+    }
+}
+
+extern "C" int svdq_maskset_indices(const svdq_maskset *ms, const void *mask_ptrs, const void *idx_true_ptrs,
+                                    const void *idx_false_ptrs, int64_t *count_true, int64_t *count_false, void *work,
+                                    void *stream) {
+    if (!ms || !mask_ptrs || !idx_true_ptrs || !count_true || !work) {
+        svdq_set_error("svdq_maskset_indices: bad argument");
+        return SVDQ_EINVAL;
+    }
+    for (int q = 0; q < ms->n_params; ++q)
+        if (ms->h_numel[q] > 0x7fffffffLL) {
+            svdq_set_error("svdq_maskset_indices: parameter %d has more than 2^31-1 elements", q);
+            return SVDQ_EUNSUPPORTED;
+        }
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *wb = reinterpret_cast<uint8_t *>(work);
+    unsigned *tile_counts = reinterpret_cast<unsigned *>(wb);
+    unsigned long long *tile_offsets =
+        reinterpret_cast<unsigned long long *>(wb + svdq_align_up((int64_t)ms->n_tiles * 4, 256));
+    auto mp = reinterpret_cast<const uint8_t *const *>(mask_ptrs);
+    hipLaunchKernelGGL(k_maskset_count, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
+                       ms->d_numel, mp, tile_counts);
+    hipLaunchKernelGGL(k_maskset_scan, dim3(ms->n_params), dim3(1024), 0, st, ms->d_tile_begin, ms->d_numel, tile_counts,
+                       tile_offsets, reinterpret_cast<long long *>(count_true),
+                       reinterpret_cast<long long *>(count_false));
+    hipLaunchKernelGGL(k_maskset_index, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
+                       ms->d_numel, mp, reinterpret_cast<int32_t *const *>(idx_true_ptrs),
+                       reinterpret_cast<int32_t *const *>(idx_false_ptrs), tile_offsets);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+extern "C" int svdq_maskset_combine_indices(const svdq_maskset *ms, const void *mask_ptrs, int32_t n_masks,
+                                            int32_t strategy, const void *out_ptrs, const void *idx_true_ptrs,
+                                            const void *idx_false_ptrs, int64_t *count_true, int64_t *count_false,
+                                            void *work, void *stream) {
+    if (!ms || !mask_ptrs || !out_ptrs || !idx_true_ptrs || !count_true || !work || n_masks < 1) {
+        svdq_set_error(n_masks < 1 ? "Empty mask list" : "svdq_maskset_combine_indices: bad argument");
+        return SVDQ_EINVAL;
+    }
+    if (strategy < 0 || strategy > 2) {
+        svdq_set_error("Unknown mask strategy: %d", strategy);
+        return SVDQ_EINVAL;
+    }
+    for (int q = 0; q < ms->n_params; ++q)
+        if (ms->h_numel[q] > 0x7fffffffLL) {
+            svdq_set_error("svdq_maskset_combine_indices: parameter %d has more than 2^31-1 elements", q);
+            return SVDQ_EUNSUPPORTED;
+        }
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *wb = reinterpret_cast<uint8_t *>(work);
+    unsigned *tile_counts = reinterpret_cast<unsigned *>(wb);
+    unsigned long long *tile_offsets =
+        reinterpret_cast<unsigned long long *>(wb + svdq_align_up((int64_t)ms->n_tiles * 4, 256));
+    hipLaunchKernelGGL(k_maskset_combine, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param,
+                       ms->d_tile_begin, ms->d_numel, reinterpret_cast<const uint8_t *const *>(mask_ptrs), n_masks,
+                       strategy, reinterpret_cast<uint8_t *const *>(out_ptrs), (unsigned long long *)nullptr,
+                       tile_counts);
+    hipLaunchKernelGGL(k_maskset_scan, dim3(ms->n_params), dim3(1024), 0, st, ms->d_tile_begin, ms->d_numel, tile_counts,
+                       tile_offsets, reinterpret_cast<long long *>(count_true),
+                       reinterpret_cast<long long *>(count_false));
+    hipLaunchKernelGGL(k_maskset_index, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
+                       ms->d_numel, reinterpret_cast<const uint8_t *const *>(out_ptrs),
+                       reinterpret_cast<int32_t *const *>(idx_true_ptrs),
+                       reinterpret_cast<int32_t *const *>(idx_false_ptrs), tile_offsets);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 

@@ -104,9 +104,63 @@ __device__ __forceinline__ void load_block(f32x4 (&v)[NTP], gfloat *(&bp)[NTP], 
     }
 }
 
+// Gather mode (masked parameters without a compaction pass): the kernels walk the COMPACTED row space and
+// fetch row j of every task from source element idx[j] (ascending positions of the set mask bits, built
+// once per mask by svdq_maskset_indices).  Outputs stay exactly as in the contiguous mode.  Indices are
+// loaded one block ahead of the data they address, so the data loads never wait for them.
+typedef const __attribute__((address_space(1))) int32_t gint;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) i32x4 gi32x4;
+
+// In gather mode lane l owns rows l, 64+l, 128+l, 192+l of a block (not 4l..4l+3): the four dword loads of a
+// task then each read 64 CONSECUTIVE compacted rows -- a nearly contiguous 256-byte run of the source -- instead
+// of every fourth row of a 1 KiB span, which would make each instruction touch the same 16 cache lines.
+__device__ __forceinline__ i32x4 load_idx(gint *idx, int64_t rb, int64_t D, int lane) {
+    const int64_t r = rb + lane;
+    i32x4 o = {-1, -1, -1, -1};
+    if (rb + SVDQ_BLK_ROWS <= D) {
+        o.x = idx[r];
+        o.y = idx[r + 64];
+        o.z = idx[r + 128];
+        o.w = idx[r + 192];
+    } else {
+        if (r < D) o.x = idx[r];
+        if (r + 64 < D) o.y = idx[r + 64];
+        if (r + 128 < D) o.z = idx[r + 128];
+        if (r + 192 < D) o.w = idx[r + 192];
+    }
+    return o;
+}
+
+template <int NTP>
+__device__ __forceinline__ void load_block_gather(f32x4 (&v)[NTP], gfloat *(&bp)[NTP], const i32x4 &ix, bool full) {
+    if (full) {
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+            f32x4 o;
+            o.x = bp[t][ix.x];
+            o.y = bp[t][ix.y];
+            o.z = bp[t][ix.z];
+            o.w = bp[t][ix.w];
+            v[t] = o;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+            f32x4 o = zero4();
+            if (ix.x >= 0) o.x = bp[t][ix.x];
+            if (ix.y >= 0) o.y = bp[t][ix.y];
+            if (ix.z >= 0) o.z = bp[t][ix.z];
+            if (ix.w >= 0) o.w = bp[t][ix.w];
+            v[t] = o;
+        }
+    }
+}
+
 // Row mean over the NT real tasks (sum in task order, then one fp32 divide: basis.py:109),
 // subtract (basis.py:111), and park the centred strip in LDS.  Padded tasks are stored as 0.
-template <int NTP>
+// STRIDED (gather mode): component e of a lane's vector is row 64 e + lane, not 4 lane + e.
+template <int NTP, bool STRIDED = false>
 __device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int center, float *X, int lane) {
     f32x4 s = zero4();
 #pragma unroll
@@ -125,7 +179,12 @@ __device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int
 #pragma unroll
     for (int t = 0; t < NTP; ++t) {
         f32x4 xc = (t < NT) ? (v[t] - mean) : zero4();
-        *reinterpret_cast<f32x4 *>(X + t * XS + 4 * lane) = xc;
+        if constexpr (STRIDED) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) X[t * XS + 64 * e + lane] = xc[e];
+        } else {
+            *reinterpret_cast<f32x4 *>(X + t * XS + 4 * lane) = xc;
+        }
     }
     return mean;
 }
@@ -133,12 +192,14 @@ __device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int
 // ------------------------------------------------------------------------------------ pass 1
 // One work unit of pass 1 (a run of 256-row blocks of one parameter) by ONE wavefront.
 // X: NTP*XS floats of wave-private LDS.
-template <int NTP>
+template <int NTP, bool GATHER = false>
 __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *__restrict__ params,
                                           const SvdqUnit *__restrict__ units,
                                           const float *const *__restrict__ ptrs,
                                           const int64_t *__restrict__ rows_dev, int NT, int center,
-                                          double *__restrict__ gram_part) {
+                                          double *__restrict__ gram_part,
+                                          const int32_t *const *__restrict__ idx_ptrs = nullptr) {
+    static_assert(!(GATHER && SVDQ_PREFETCH2), "gather mode supports the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
     constexpr int NACC = (NB == 1) ? 1 : 3;  // AA | AA, AB, BB
@@ -165,16 +226,34 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     // The loads of the next block (or next two, SVDQ_PREFETCH2) are in flight while a block is computed.
     constexpr int AHEAD = SVDQ_PREFETCH2 ? 2 : 1;
     f32x4 v0[NTP];
-    if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
+    gint *gidx = nullptr;
+    i32x4 ixn = {-1, -1, -1, -1};  // indices of the block after the one whose data is in flight
+    if constexpr (GATHER) {
+        gidx = (gint *)idx_ptrs[p];
+        if (r_begin < r_end) {
+            const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
+            load_block_gather<NTP>(v0, bp, ix0, r_begin + SVDQ_BLK_ROWS <= D);
+            if (r_begin + SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, r_begin + SVDQ_BLK_ROWS, D, lane);
+        }
+    } else {
+        if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
+    }
 #if SVDQ_PREFETCH2
     f32x4 v1[NTP];
     if (r_begin + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v1, bp, r_begin + SVDQ_BLK_ROWS, D, lane);
 #endif
 
     auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
-        center_store<NTP>(v, NT, center, X, lane);
+        center_store<NTP, GATHER>(v, NT, center, X, lane);
         wave_sync();
-        if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
+        if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
+            if constexpr (GATHER) {
+                load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
+                if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
+            } else {
+                load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
+            }
+        }
 
         f32x4 acc[NACC];
 #pragma unroll
@@ -256,14 +335,15 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
     }
 }
 
-template <int NTP>
+template <int NTP, bool GATHER>
 __global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ params,
                                              const SvdqUnit *__restrict__ units,
                                              const float *const *__restrict__ ptrs,
                                              const int64_t *__restrict__ rows_dev, int NT, int center,
-                                             double *__restrict__ gram_part, int unit0) {
+                                             double *__restrict__ gram_part, int unit0,
+                                             const int32_t *const *__restrict__ idx_ptrs) {
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
-    gram_unit<NTP>(X, unit0 + (int)blockIdx.x, params, units, ptrs, rows_dev, NT, center, gram_part);
+    gram_unit<NTP, GATHER>(X, unit0 + (int)blockIdx.x, params, units, ptrs, rows_dev, NT, center, gram_part, idx_ptrs);
 }
 
 // ------------------------------------------------------------------------------------ pass 2
@@ -311,13 +391,14 @@ __device__ __forceinline__ bf16x8 pack_bf16(const f32x4 &lo, const f32x4 &hi) {
 // 2^-12 term is 2^-21 of c, below the fp32 accumulation noise of the direct product.
 // One work unit of pass 2 by ONE wavefront.  X: NTP*XS floats, OUT: SVDQ_BLK_ROWS*NTP + 16 elements of
 // wave-private LDS.
-template <int NTP, bool OUT16>
+template <int NTP, bool OUT16, bool GATHER = false>
 __device__ __forceinline__ void bp_unit(
     float *X, typename OutT<OUT16>::type *OUT, int uidx, const SvdqParam *__restrict__ params,
     const SvdqUnit *__restrict__ units, const float *const *__restrict__ ptrs,
     const int64_t *__restrict__ rows_dev, int NT, int center, const float *__restrict__ Wtab,
     const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev, uint8_t *__restrict__ basis,
-    float *__restrict__ meanbuf, double *__restrict__ cpart) {
+    float *__restrict__ meanbuf, double *__restrict__ cpart, const int32_t *const *__restrict__ idx_ptrs = nullptr) {
+    static_assert(!(GATHER && SVDQ_PREFETCH2), "gather mode supports the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
     constexpr int KS = NTP / 4;
@@ -398,30 +479,54 @@ __device__ __forceinline__ void bp_unit(
     // The loads of the next block (or next two, SVDQ_PREFETCH2) are in flight while a block is computed.
     constexpr int AHEAD = SVDQ_PREFETCH2 ? 2 : 1;
     f32x4 v0[NTP];
-    if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
+    gint *gidx = nullptr;
+    i32x4 ixn = {-1, -1, -1, -1};  // indices of the block after the one whose data is in flight
+    if constexpr (GATHER) {
+        gidx = (gint *)idx_ptrs[p];
+        if (r_begin < r_end) {
+            const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
+            load_block_gather<NTP>(v0, bp, ix0, r_begin + SVDQ_BLK_ROWS <= D);
+            if (r_begin + SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, r_begin + SVDQ_BLK_ROWS, D, lane);
+        }
+    } else {
+        if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
+    }
 #if SVDQ_PREFETCH2
     f32x4 v1[NTP];
     if (r_begin + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v1, bp, r_begin + SVDQ_BLK_ROWS, D, lane);
 #endif
 
     auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
-        const f32x4 mean = center_store<NTP>(v, NT, center, X, lane);
+        const f32x4 mean = center_store<NTP, GATHER>(v, NT, center, X, lane);
 #ifdef SVDQ_ABLATE_STORES
         if (gmean && D < 0) {
 #else
         if (gmean) {
 #endif
-            const int64_t rr = rb + 4 * lane;
-            if (rr + 3 < D) {
-                *reinterpret_cast<f32x4 *>(gmean + rr) = mean;
+            if constexpr (GATHER) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (rb + 64 * e + lane < D) gmean[rb + 64 * e + lane] = mean[e];
             } else {
-                if (rr < D) gmean[rr] = mean.x;
-                if (rr + 1 < D) gmean[rr + 1] = mean.y;
-                if (rr + 2 < D) gmean[rr + 2] = mean.z;
+                const int64_t rr = rb + 4 * lane;
+                if (rr + 3 < D) {
+                    *reinterpret_cast<f32x4 *>(gmean + rr) = mean;
+                } else {
+                    if (rr < D) gmean[rr] = mean.x;
+                    if (rr + 1 < D) gmean[rr + 1] = mean.y;
+                    if (rr + 2 < D) gmean[rr + 2] = mean.z;
+                }
             }
         }
         wave_sync();
-        if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
+        if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
+            if constexpr (GATHER) {
+                load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
+                if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
+            } else {
+                load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
+            }
+        }
 
         f32x4 cf[NCB];
 #pragma unroll
@@ -551,18 +656,19 @@ UNROLL_N(SVDQ_UNROLL_BP)
     }
 }
 
-template <int NTP, bool OUT16>
+template <int NTP, bool OUT16, bool GATHER>
 __global__ __launch_bounds__(64) void k_basis_project(
     const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
     const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
     const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
-    uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse) {
+    uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse,
+    const int32_t *const *__restrict__ idx_ptrs) {
     using out_t = typename OutT<OUT16>::type;
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
     __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];  // +16: dump slot for idle lanes
     const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
-    bp_unit<NTP, OUT16>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis, meanbuf,
-                        cpart);
+    bp_unit<NTP, OUT16, GATHER>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis,
+                                meanbuf, cpart, idx_ptrs);
 }
 
 // ------------------------------------------------------------------------------------ fused schedule
@@ -745,24 +851,30 @@ int svdq_launch_fused(const svdq_plan *pl, const void *ptrs, const int64_t *rows
 // ------------------------------------------------------------------------------------ launchers
 template <int NTP>
 static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                         int unit0, int nunits, int center, hipStream_t st) {
-    hipLaunchKernelGGL(k_gram<NTP>, dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units,
-                       reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks, center,
-                       gram_part, unit0);
+                         int unit0, int nunits, int center, const void *idx, hipStream_t st) {
+    auto ip = reinterpret_cast<const int32_t *const *>(idx);
+    if (idx)
+        hipLaunchKernelGGL((k_gram<NTP, true>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units,
+                           reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks, center, gram_part, unit0,
+                           ip);
+    else
+        hipLaunchKernelGGL((k_gram<NTP, false>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units,
+                           reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks, center, gram_part, unit0,
+                           ip);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                     int unit0, int nunits, int center, hipStream_t st) {
+                     int unit0, int nunits, int center, const void *idx, hipStream_t st) {
     switch (pl->ntp) {
-        case 4: return launch_gram_t<4>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
-        case 8: return launch_gram_t<8>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
-        case 12: return launch_gram_t<12>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
-        case 16: return launch_gram_t<16>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
-        case 20: return launch_gram_t<20>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
-        case 24: return launch_gram_t<24>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
-        case 28: return launch_gram_t<28>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
-        case 32: return launch_gram_t<32>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, st);
+        case 4: return launch_gram_t<4>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
+        case 8: return launch_gram_t<8>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
+        case 12: return launch_gram_t<12>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
+        case 16: return launch_gram_t<16>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
+        case 20: return launch_gram_t<20>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
+        case 24: return launch_gram_t<24>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
+        case 28: return launch_gram_t<28>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
+        case 32: return launch_gram_t<32>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
     }
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;
@@ -771,31 +883,33 @@ int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
 template <int NTP>
 static int launch_bp_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                        const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
-                       int unit0, int nunits, int reverse, hipStream_t st) {
+                       int unit0, int nunits, int reverse, const void *idx, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
-    if (pl->cfg.fp16)
-        hipLaunchKernelGGL((k_basis_project<NTP, true>), dim3(nunits), dim3(64), 0, st, pl->d_params,
-                           pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,
-                           cpart, unit0, reverse);
-    else
-        hipLaunchKernelGGL((k_basis_project<NTP, false>), dim3(nunits), dim3(64), 0, st, pl->d_params,
-                           pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,
-                           cpart, unit0, reverse);
+    auto ip = reinterpret_cast<const int32_t *const *>(idx);
+#define SVDQ_LAUNCH_BP(F16, G)                                                                                   \
+    hipLaunchKernelGGL((k_basis_project<NTP, F16, G>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, \
+                       rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean, cpart, unit0, reverse, ip)
+    if (pl->cfg.fp16) {
+        if (idx) SVDQ_LAUNCH_BP(true, true); else SVDQ_LAUNCH_BP(true, false);
+    } else {
+        if (idx) SVDQ_LAUNCH_BP(false, true); else SVDQ_LAUNCH_BP(false, false);
+    }
+#undef SVDQ_LAUNCH_BP
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
-                              double *cpart, int unit0, int nunits, int reverse, hipStream_t st) {
+                              double *cpart, int unit0, int nunits, int reverse, const void *idx, hipStream_t st) {
     switch (pl->ntp) {
-        case 4: return launch_bp_t<4>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
-        case 8: return launch_bp_t<8>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
-        case 12: return launch_bp_t<12>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
-        case 16: return launch_bp_t<16>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
-        case 20: return launch_bp_t<20>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
-        case 24: return launch_bp_t<24>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
-        case 28: return launch_bp_t<28>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
-        case 32: return launch_bp_t<32>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, st);
+        case 4: return launch_bp_t<4>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
+        case 8: return launch_bp_t<8>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
+        case 12: return launch_bp_t<12>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
+        case 16: return launch_bp_t<16>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
+        case 20: return launch_bp_t<20>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
+        case 24: return launch_bp_t<24>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
+        case 28: return launch_bp_t<28>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
+        case 32: return launch_bp_t<32>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
     }
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;

@@ -29,7 +29,7 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
     min_size = int(config.svd_min_mask_size)
 
     # group regions by the number of tasks that have the parameter (one plan per N)
-    groups: Dict[int, List[dict]] = {}
+    groups: Dict[Tuple[int, bool], List[dict]] = {}   # (tasks present, gather mode) -> regions of one plan
     keep = []
     with torch.cuda.device(dev):
         masked_by_n: Dict[int, List[tuple]] = {}
@@ -45,29 +45,31 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
                 vs = [prepare_vector(d, dev) for d in deltas]
                 if vs[0].numel() == 0:
                     continue
-                groups.setdefault(len(present), []).append(
+                groups.setdefault((len(present), False), []).append(
                     {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": None,
                      "upper": vs[0].numel(), "min": 0})
-        # every masked parameter of a group goes through ONE batched compaction (signal and, when asked,
-        # noise in the same pass); mask.sum() stays on the device and becomes rows_dev
+        # every masked parameter of a group gets ONE batched index build (signal and, when asked, noise in the same
+        # pass): the compressor then reads the original task tensors through the index lists (gather mode), so no
+        # compacted copies of the deltas are ever written; mask.sum() stays on the device and becomes rows_dev
         for n_present, items in masked_by_n.items():
             ms = ml.MaskSet([it[3].numel() for it in items], dev)
-            dt, df, ct, cf = ms.compact([it[3] for it in items], [it[2] for it in items], want_false=include_noise)
-            keep.append((ms, dt, df))
-            for q, (name, present, _, _) in enumerate(items):
-                groups.setdefault(n_present, []).append(
-                    {"name": name, "region": "masked", "tasks": present, "vectors": dt[q], "count": ct[q:q + 1],
-                     "upper": dt[q][0].numel(), "min": min_size})
+            it_, if_, ct, cf = ms.indices([it[3] for it in items], want_false=include_noise)
+            keep.append((ms, it_, if_))
+            for q, (name, present, deltas, _) in enumerate(items):
+                vs = [prepare_vector(d, dev) for d in deltas]
+                groups.setdefault((n_present, True), []).append(
+                    {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": ct[q:q + 1],
+                     "upper": vs[0].numel(), "min": min_size, "index": it_[q]})
                 if include_noise:
-                    groups.setdefault(n_present, []).append(
-                        {"name": name, "region": "noise", "tasks": present, "vectors": df[q], "count": cf[q:q + 1],
-                         "upper": df[q][0].numel(), "min": 1, "gate": ct[q:q + 1]})
+                    groups.setdefault((n_present, True), []).append(
+                        {"name": name, "region": "noise", "tasks": present, "vectors": vs, "count": cf[q:q + 1],
+                         "upper": vs[0].numel(), "min": 1, "gate": ct[q:q + 1], "index": if_[q]})
         order = {n: i for i, n in enumerate(names)}
         for lst in groups.values():
             lst.sort(key=lambda e: (order[e["name"]], e["region"] != "masked"))
 
         bases: Dict[str, Dict] = {}
-        for n_tasks, entries in groups.items():
+        for (n_tasks, gather), entries in groups.items():
             entries = [e for e in entries if e["upper"] > 0]
             if not entries:
                 continue
@@ -90,7 +92,11 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
                         parts.append(torch.where(ok, c, torch.zeros_like(c)))
                 rows_dev = torch.cat(parts)
             table = plan.pointer_table([e["vectors"] for e in entries])
-            plan.run(table, rows_dev)
+            if gather:
+                itab = torch.tensor([e["index"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
+                plan.run_gather(table, itab, rows_dev)
+            else:
+                plan.run(table, rows_dev)
             small = plan.fetch_small()
             batch = BatchResult(plan, small, [(e["name"], e["region"]) for e in entries],
                                 [e["tasks"] for e in entries])

@@ -109,6 +109,49 @@ class MaskSet:
                                                     x["n_src"], _ptr(x["ct"]), _ptr(x["cf"]), _ptr(self.work),
                                                     _stream_ptr()), "svdq_maskset_compact")
 
+    def prepare_indices(self, masks, want_false: bool):
+        mb = [_as_mask_bytes(m, self.device) for m in masks]
+        for q in range(self.Q):
+            if mb[q].numel() != self.numels[q]:
+                raise ValueError(f"Shape mismatch: tensor vs mask for parameter {q}")
+        it = [torch.empty(self.numels[q], dtype=torch.int32, device=self.device) for q in range(self.Q)]
+        if_ = [torch.empty(self.numels[q], dtype=torch.int32, device=self.device) for q in range(self.Q)] \
+            if want_false else None
+        ct = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        cf = torch.zeros(self.Q, dtype=torch.int64, device=self.device) if want_false else None
+        self._i = dict(mb=mb, it=it, if_=if_, ct=ct, cf=cf, mt=self._table(mb), tt=self._table(it),
+                       ft=self._table(if_) if want_false else None)
+        return it, if_, ct, cf
+
+    def run_indices(self):
+        x = self._i
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_indices(self._h, _ptr(x["mt"]), _ptr(x["tt"]), _ptr(x["ft"]), _ptr(x["ct"]),
+                                                    _ptr(x["cf"]), _ptr(self.work), _stream_ptr()),
+                      "svdq_maskset_indices")
+
+    def prepare_combine_indices(self, masks_per_param, strategy: str, want_false: bool):
+        """combine + index build on the combined masks in 3 launches (the combine pass supplies the tile counts)."""
+        outs, _ = self.prepare_combine(masks_per_param, strategy)
+        it, if_, ct, cf = self.prepare_indices([o.view(torch.bool) for o in outs], want_false)
+        return outs, it, if_, ct, cf
+
+    def run_combine_indices(self):
+        c, x = self._c, self._i
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_combine_indices(self._h, _ptr(c["mt"]), c["n"], c["strategy"], _ptr(c["ot"]),
+                                                            _ptr(x["tt"]), _ptr(x["ft"]), _ptr(x["ct"]), _ptr(x["cf"]),
+                                                            _ptr(self.work), _stream_ptr()),
+                      "svdq_maskset_combine_indices")
+
+    def indices(self, masks, want_false: bool):
+        """Ascending flat positions (int32) of the set / cleared elements of every mask: what the gather mode
+        of the compressor reads the task deltas through, instead of 2 N compacted copies per parameter.
+        Returns (idx_true[q], idx_false[q] | None, count_true [Q], count_false [Q] | None)."""
+        out = self.prepare_indices(masks, want_false)
+        self.run_indices()
+        return out
+
     def compact(self, masks, srcs_per_param, want_false: bool):
         """masks[q]: combined mask; srcs_per_param[q]: list of n_src fp32 tensors of that shape.
         Returns (dst_true[q][s], dst_false[q][s] | None, count_true [Q], count_false [Q] | None);

@@ -189,6 +189,14 @@ class CompressPlan:
         nat.check(self.lib.svdq_compress(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.workspace), _ptr(self.small),
                                          _ptr(self.basis), _ptr(self.mean), _stream_ptr()), "svdq_compress")
 
+    def run_gather(self, table, index_table, rows_dev):
+        """run() for masked parameters without compacted copies: ``table`` names the ORIGINAL full-size task
+        tensors, ``index_table`` (device int64 [P]) the int32 index lists of the selected elements
+        (MaskSet.indices), ``rows_dev`` their counts."""
+        nat.check(self.lib.svdq_compress_gather(self._h, _ptr(table), _ptr(index_table), _ptr(rows_dev),
+                                                _ptr(self.workspace), _ptr(self.small), _ptr(self.basis),
+                                                _ptr(self.mean), _stream_ptr()), "svdq_compress_gather")
+
     # ---- outputs
     def fetch_small(self) -> SmallArtifacts:
         host = self.small.cpu().numpy()  # the one D2H copy (synchronises the stream)

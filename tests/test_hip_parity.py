@@ -430,6 +430,70 @@ def test_fused_schedule_bit_identical(sq, orc, N, fp16, lag_mb):
         assert torch.equal(fus.small, first)
 
 
+@pytest.mark.parametrize("N,fp16,density", [(8, True, 0.94), (8, True, 0.2), (5, False, 0.6), (20, True, 0.9)])
+def test_gather_mode_bit_identical(sq, orc, N, fp16, density):
+    """svdq_compress_gather (task deltas read through the mask's index list, no compacted copies) produces
+    exactly the artifacts of svdq_compress on the compacted tensors -- signal and noise regions alike."""
+    from svdq_amd.pipeline import CompressPlan
+    from svdq_amd.mask_loader import MaskSet
+    dev = torch.device("cuda", 0)
+    sizes = [300000, 777, 70001, 1024 * 96, 5000, 262144 + 3, 12]
+    g = torch.Generator().manual_seed(17)
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 290 + i)] for i, D in enumerate(sizes)]
+    masks = [(torch.rand(D, generator=g) < density).to(dev) for D in sizes]
+    masks[4][:] = True                                   # a fully selected and
+    masks[6][:] = False                                  # an empty mask
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=fp16, low_bits=4, rtvq_stages=2, device=dev,
+              unit_rows=1024)
+    ms = MaskSet(sizes, dev)
+    dt, df, ct, cf = ms.compact(masks, vecs, want_false=True)
+    it, if_, ct2, cf2 = ms.indices(masks, want_false=True)
+    assert torch.equal(ct, ct2) and torch.equal(cf, cf2)
+    for q, D in enumerate(sizes):
+        n = int(ct[q])
+        assert torch.equal(it[q][:n].long(), torch.nonzero(masks[q]).flatten())
+        assert torch.equal(if_[q][:D - n].long(), torch.nonzero(~masks[q]).flatten())
+    for compacted, idx, cnt in ((dt, it, ct), (df, if_, cf)):
+        ref = CompressPlan(sizes, N, **kw)
+        ref.run(ref.pointer_table(compacted), cnt)
+        gat = CompressPlan(sizes, N, **kw)
+        itab = torch.tensor([x.data_ptr() for x in idx], dtype=torch.int64).to(dev)
+        gat.run_gather(gat.pointer_table(vecs), itab, cnt)
+        torch.cuda.synchronize()
+        sm, sg = ref.fetch_small(), gat.fetch_small()
+        assert torch.equal(gat.small, ref.small)
+        for p in range(len(sizes)):
+            rows = int(sm.rows[p])
+            assert rows == int(cnt[p])
+            a = ref.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), rows)
+            b = gat.basis_tensors(p, int(sg.k[p]), int(sg.r[p]), rows)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("strategy", ["union", "intersection", "majority"])
+def test_combine_indices_equals_combine_then_indices(sq, strategy):
+    from svdq_amd.mask_loader import MaskSet
+    dev = torch.device("cuda", 0)
+    sizes = [300001, 777, 2048 * 5, 12]
+    g = torch.Generator().manual_seed(23)
+    per_task = [[(torch.rand(D, generator=g) > 0.6).to(dev) for _ in range(5)] for D in sizes]
+    a = MaskSet(sizes, dev)
+    comb, counts = a.combine(per_task, strategy)
+    it, if_, ct, cf = a.indices([c.view(torch.bool) for c in comb], want_false=True)
+    b = MaskSet(sizes, dev)
+    outs, it2, if2, ct2, cf2 = b.prepare_combine_indices(per_task, strategy, want_false=True)
+    b.run_combine_indices()
+    torch.cuda.synchronize()
+    assert torch.equal(ct, ct2) and torch.equal(cf, cf2) and torch.equal(counts, ct2)
+    for q, D in enumerate(sizes):
+        stack = torch.stack([m.to(torch.int32) for m in per_task[q]]).sum(0)
+        want = {"union": stack > 0, "intersection": stack == 5, "majority": 2 * stack >= 5}[strategy]
+        assert torch.equal(outs[q].view(torch.bool), want) and torch.equal(comb[q], outs[q])
+        n = int(ct[q])
+        assert torch.equal(it[q][:n], it2[q][:n]) and torch.equal(if_[q][:D - n], if2[q][:D - n])
+        assert torch.equal(it2[q][:n].long(), torch.nonzero(want).flatten())
+
+
 # ------------------------------------------------------------------------------- masks
 def test_masks_vs_reference_vectors(sq):
     g = load_golden("masks.npz")
