@@ -41,6 +41,7 @@ from .ingest import ElementwiseBatch, ingest_state_dicts, quantize_state_dict, d
 from .driver import build_bases, run_basis_and_compress
 from .pipeline import CompressPlan, compress_batch
 from . import cli
+from . import torch_ops   # registers torch.ops.svdq.*
 
 # aliases named by BASELINE.json's north_star (quantization_utils.py)
 dequantize_asymmetric = asymmetric_dequantization

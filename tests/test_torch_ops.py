@@ -1,0 +1,58 @@
+"""torch.ops.svdq.* -- the custom-operator face of the C ABI (BASELINE north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import svdq_amd  # noqa: F401  (registers the operators)
+
+OPS = ("rtvq_quantize", "rtvq_dequantize", "mask_combine", "mask_select", "compress", "ingest", "task_gram")
+
+
+def test_ops_are_registered_and_have_no_cpu_kernel():
+    for name in OPS:
+        assert hasattr(torch.ops.svdq, name), name
+    # there is no CPU implementation to fall back to: CPU tensors are refused by the dispatcher
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.svdq.rtvq_quantize(torch.randn(16), 4, 2)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.svdq.mask_combine([torch.ones(4, dtype=torch.bool)], "union")
+
+
+@pytest.mark.gpu
+def test_ops_match_the_python_layer():
+    from oracle import svd_hybrid_oracle as orc
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(4)
+    x = 0.02 * torch.randn(100003, device=dev)
+    codes, scale, zp, rn = torch.ops.svdq.rtvq_quantize(x, 4, 2)
+    want = orc.rtvq_quantize(x.cpu().numpy(), 4, 2)
+    assert np.array_equal(codes.cpu().numpy(), want["codes"])
+    assert np.array_equal(scale.cpu().numpy(), want["scale"]) and np.array_equal(zp.cpu().numpy(), want["zero_point"])
+    deq = torch.ops.svdq.rtvq_dequantize(codes, scale, zp)
+    assert np.array_equal(deq.cpu().numpy(), orc.rtvq_dequantize(want).reshape(-1))
+    masks = [torch.rand(5000, device=dev) > 0.5 for _ in range(3)]
+    u = torch.ops.svdq.mask_combine(masks, "union")
+    assert torch.equal(u, masks[0] | masks[1] | masks[2])
+    assert torch.equal(torch.ops.svdq.mask_select(x[:5000], u, False), x[:5000][u])
+    assert torch.equal(torch.ops.svdq.mask_select(x[:5000], u, True), x[:5000][~u])
+    N, sizes = 8, [70001, 768]
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 40 + i)] for i, D in enumerate(sizes)]
+    small, basis, mean = torch.ops.svdq.compress([v for vs in vecs for v in vs], N, 0.9, 0, True, True, 4, 2)
+    plan = CompressPlan(sizes, N, energy_threshold=0.9, max_rank=None, center=True, fp16=True, low_bits=4,
+                        rtvq_stages=2, device=dev)
+    plan.run(plan.pointer_table(vecs))
+    torch.cuda.synchronize()
+    assert torch.equal(small, plan.small) and mean.numel() == plan.mean.numel()
+    sm = plan.fetch_small()
+    for p, D in enumerate(sizes):
+        a = plan.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), D)
+        lo = plan.slab_off[p]
+        assert torch.equal(basis[lo:lo + a[0].numel() * 2].view(torch.float16).view(a[0].shape), a[0])
+    base = torch.randn(33, 7, device=dev)
+    fts = [base + 0.1 * torch.randn_like(base) for _ in range(3)]
+    for d, f in zip(torch.ops.svdq.ingest(base, fts), fts):
+        assert torch.equal(d, f - base)
+    G = torch.ops.svdq.task_gram([v for vs in vecs for v in vs], N)
+    ref = sum(torch.stack(vs).double() @ torch.stack(vs).double().T for vs in vecs)
+    assert torch.allclose(G, ref, rtol=2e-6, atol=2e-6 * float(ref.abs().max()))
