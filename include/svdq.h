@@ -100,6 +100,11 @@ const char *svdq_last_error(void);
 int  svdq_plan_create(svdq_plan **plan, int32_t n_tasks, int32_t n_params, const int64_t *rows,
                       const svdq_config *cfg);
 void svdq_plan_destroy(svdq_plan *plan);
+/* Per-parameter code width for the low-energy coefficients (host array [n_params], each in [1, 8]); NULL
+ * restores cfg.low_bits for every parameter.  The reference builds ONE RTVQQuantizer(config.svd_low_bits, ...)
+ * per run (compress.py:180-183); BASELINE config #5's "mixed 8-bit / 2-bit" run is two quantizer instances over
+ * a partition of the parameters, which this expresses inside one plan. */
+int  svdq_plan_set_low_bits(svdq_plan *plan, const int32_t *bits);
 int  svdq_plan_sizes(const svdq_plan *plan, svdq_sizes *out);
 int  svdq_plan_small_layout(const svdq_plan *plan, svdq_small_layout *out);
 /* Per parameter: byte offset of its slab in the packed basis buffer and float offset of its

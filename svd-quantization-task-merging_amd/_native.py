@@ -44,6 +44,7 @@ SIGNATURES = {
     "svdq_last_error": (c_char_p, []),
     "svdq_plan_create": (c_int32, [POINTER(c_void_p), c_int32, c_int32, POINTER(c_int64), POINTER(SvdqConfig)]),
     "svdq_plan_destroy": (None, [c_void_p]),
+    "svdq_plan_set_low_bits": (c_int32, [c_void_p, POINTER(c_int32)]),
     "svdq_plan_sizes": (c_int32, [c_void_p, POINTER(SvdqSizes)]),
     "svdq_plan_small_layout": (c_int32, [c_void_p, POINTER(SvdqSmallLayout)]),
     "svdq_plan_basis_layout": (c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),

@@ -4,7 +4,7 @@ dataclass (reference src/svd_hybrid/config.py:157-234), so existing call sites k
 Only the fields the hot path reads are interpreted here; the rest are carried through.
 """
 from dataclasses import dataclass, field
-from typing import List, Optional
+from typing import Callable, List, Optional
 
 
 @dataclass
@@ -34,6 +34,8 @@ class SVDHybridConfig:
     output_dir: str = "./svd_hybrid_output"
     artifact_dir: str = "./artifacts"
     device: str = "cuda"
+    # extension (not in the reference): name -> code width, for a run that mixes widths (BASELINE config #5)
+    svd_low_bits_by_param: Optional[Callable[[str], int]] = None
 
     def __post_init__(self):
         if self.svd_mask_strategy not in ("union", "intersection", "majority"):

@@ -270,6 +270,7 @@ extern "C" void svdq_plan_destroy(svdq_plan *pl) {
     if (!pl) return;
     if (pl->d_params) (void)hipFree(pl->d_params);
     if (pl->d_units) (void)hipFree(pl->d_units);
+    if (pl->d_bits) (void)hipFree(pl->d_bits);
     if (pl->d_items) (void)hipFree(pl->d_items);
     if (pl->d_ctl) (void)hipFree(pl->d_ctl);
     for (int g = 0; g < pl->n_groups; ++g) {
@@ -289,6 +290,23 @@ extern "C" void svdq_plan_destroy(svdq_plan *pl) {
     free(pl->h_params);
     free(pl->h_units);
     free(pl);
+}
+
+extern "C" int svdq_plan_set_low_bits(svdq_plan *pl, const int32_t *bits) {
+    if (!pl) return SVDQ_EINVAL;
+    if (!bits) {   // back to one width for the whole plan
+        if (pl->d_bits) (void)hipFree(pl->d_bits);
+        pl->d_bits = nullptr;
+        return SVDQ_OK;
+    }
+    for (int p = 0; p < pl->n_params; ++p)
+        if (bits[p] < 1 || bits[p] > 8) {
+            svdq_set_error("Low bits must be in [1, 8], got %d (parameter %d)", bits[p], p);
+            return SVDQ_EINVAL;
+        }
+    if (!pl->d_bits) HIP_TRY(hipMalloc((void **)&pl->d_bits, sizeof(int32_t) * pl->n_params));
+    HIP_TRY(hipMemcpy(pl->d_bits, bits, sizeof(int32_t) * pl->n_params, hipMemcpyHostToDevice));
+    return SVDQ_OK;
 }
 
 extern "C" int svdq_plan_sizes(const svdq_plan *pl, svdq_sizes *out) {

@@ -58,6 +58,7 @@ struct svdq_plan {
     hipStream_t side[SVDQ_NSIDE];
     // optional fused persistent schedule (cfg.reserved bit 2; bits 8..23 = lag in MB between the Gram and the
     // projection of a parameter): item queue and the zero-initialised control block
+    int32_t *d_bits;  // optional per-parameter low_bits (svdq_plan_set_low_bits), NULL = cfg.low_bits everywhere
     int32_t fused, n_items;
     int32_t *d_items, *d_ctl;
     int64_t ctl_bytes;

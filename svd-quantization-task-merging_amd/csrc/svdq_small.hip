@@ -116,13 +116,15 @@ __global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restri
                                                        const int32_t *__restrict__ r_in,
                                                        float *__restrict__ coef_out, uint16_t *__restrict__ chigh_out,
                                                        uint8_t *__restrict__ codes_out, float *__restrict__ scale_out,
-                                                       float *__restrict__ zp_out, float *__restrict__ rnorm_out, int param0) {
+                                                       float *__restrict__ zp_out, float *__restrict__ rnorm_out, int param0,
+                                                       const int32_t *__restrict__ bits_tab) {
     __shared__ double red[4 * 1024];
     __shared__ double C[1024];
     __shared__ float res[32 * LDN];
 
     const int p = param0 + blockIdx.x, tid = threadIdx.x, n = NT;
     const SvdqParam pd = params[p];
+    if (bits_tab) bits = bits_tab[p];   // per-parameter code width (config #5's mixed 8-bit / 2-bit run)
     (void)pack;
     (void)pd;
     reduce_partials(cpart, p * SVDQ_RC, (p + 1) * SVDQ_RC, n * n, red, C);  // level-2 partials of k_reduce
@@ -215,6 +217,6 @@ int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, const double *c0
                        reinterpret_cast<const int32_t *>(small + L.r_off), reinterpret_cast<float *>(small + L.coef_off),
                        reinterpret_cast<uint16_t *>(small + L.chigh_off), small + L.codes_off,
                        reinterpret_cast<float *>(small + L.scale_off), reinterpret_cast<float *>(small + L.zp_off),
-                       reinterpret_cast<float *>(small + L.rnorm_off), param0);
+                       reinterpret_cast<float *>(small + L.rnorm_off), param0, pl->d_bits);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }

@@ -153,6 +153,7 @@ def compute_compression_statistics(task_vectors: Dict[str, Dict[str, torch.Tenso
     ceil(n * bits / 8) + 8 B of scale/zero-point."""
     import math
     bits, stages = config.svd_low_bits, config.svd_rtvq_stages
+    by_param = getattr(config, "svd_low_bits_by_param", None)   # mixed-width runs (extension, config #5)
     orig_task = {t: sum(d.numel() * 4 for d in tv.values()) for t, tv in task_vectors.items()}
     first = task_vectors[next(iter(task_vectors))]
     orig_param = {n: sum(tv[n].numel() * 4 for tv in task_vectors.values() if n in tv) for n in first.keys()}
@@ -173,7 +174,8 @@ def compute_compression_statistics(task_vectors: Dict[str, Dict[str, torch.Tenso
                     continue
                 ma = art["masked"]
                 b16 = ma["c_high_fp16"].numel() * 2
-                bq = sum(math.ceil(p["quantized"].numel() * bits / 8) + 8 for p in ma["c_low_quant"].get("payloads", []))
+                pb = int(by_param(name)) if by_param else bits
+                bq = sum(math.ceil(p["quantized"].numel() * pb / 8) + 8 for p in ma["c_low_quant"].get("payloads", []))
                 ps["fp16_high_energy_bytes"] += b16
                 ps["rtvq_low_energy_bytes"] += bq
                 tot["fp16"] += b16

@@ -27,6 +27,9 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
     tasks = list(task_vectors.keys())
     include_noise = bool(config.svd_include_noise)
     min_size = int(config.svd_min_mask_size)
+    # optional partition of the parameters by code width (BASELINE config #5, "mixed 8-bit / 2-bit"): a callable
+    # name -> bits on the config; the reference itself has one width per run (compress.py:180-183)
+    bits_by_param = getattr(config, "svd_low_bits_by_param", None)
 
     # group regions by the number of tasks that have the parameter (one plan per N)
     groups: Dict[Tuple[int, bool], List[dict]] = {}   # (tasks present, gather mode) -> regions of one plan
@@ -75,7 +78,9 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
                 continue
             plan = CompressPlan([e["upper"] for e in entries], n_tasks,
                                 energy_threshold=config.svd_energy_threshold, max_rank=config.svd_max_rank,
-                                center=config.svd_center, fp16=config.svd_fp16, low_bits=config.svd_low_bits,
+                                center=config.svd_center, fp16=config.svd_fp16,
+                                low_bits=([int(bits_by_param(e["name"])) for e in entries] if bits_by_param
+                                          else config.svd_low_bits),
                                 rtvq_stages=config.svd_rtvq_stages, device=dev)
             rows_dev = None
             if any(e["count"] is not None for e in entries):
@@ -120,7 +125,9 @@ def artifacts_from_batch(name: str, basis: Dict, task_vectors, config) -> Option
     if bm is None or _BATCH_KEY not in bm:
         return None
     batch, i = bm[_BATCH_KEY]
-    if (batch.plan.bits, batch.plan.S) != (config.svd_low_bits, config.svd_rtvq_stages):
+    want_bits = getattr(config, "svd_low_bits_by_param", None)
+    want_bits = int(want_bits(name)) if want_bits else config.svd_low_bits
+    if (batch.plan.bits_of(i), batch.plan.S) != (want_bits, config.svd_rtvq_stages):
         return None
     out = {}
     tasks_i = batch.task_names[i]

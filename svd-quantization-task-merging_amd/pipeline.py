@@ -81,6 +81,11 @@ class CompressPlan:
         self.P = len(self.rows)
         self.N = int(n_tasks)
         self.S = int(rtvq_stages)
+        # low_bits may be one width or one per parameter (config #5's mixed 8-bit / 2-bit run)
+        self.bits_list = [int(b) for b in low_bits] if isinstance(low_bits, (list, tuple)) else None
+        if self.bits_list is not None and len(self.bits_list) != len(self.rows):
+            raise ValueError("low_bits list needs one entry per parameter")
+        low_bits = self.bits_list[0] if self.bits_list else low_bits
         self.bits = int(low_bits)
         self.fp16 = bool(fp16)
         self.center = bool(center)
@@ -91,6 +96,11 @@ class CompressPlan:
         with torch.cuda.device(self.device):
             nat.check(self.lib.svdq_plan_create(byref(self._h), self.N, self.P, rows_arr, byref(self.cfg)),
                       "svdq_plan_create")
+        if self.bits_list is not None:
+            from ctypes import c_int32
+            arr = (c_int32 * self.P)(*self.bits_list)
+            with torch.cuda.device(self.device):
+                nat.check(self.lib.svdq_plan_set_low_bits(self._h, arr), "svdq_plan_set_low_bits")
         self.sizes = nat.SvdqSizes()
         nat.check(self.lib.svdq_plan_sizes(self._h, byref(self.sizes)), "svdq_plan_sizes")
         self.layout = nat.SvdqSmallLayout()
@@ -110,6 +120,9 @@ class CompressPlan:
         self._keep = None
 
     # ---- lifetime
+    def bits_of(self, p: int) -> int:
+        return self.bits_list[p] if self.bits_list is not None else self.bits
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.svdq_plan_destroy(self._h)
@@ -267,7 +280,7 @@ def task_artifact(plan: CompressPlan, sm: SmallArtifacts, p: int, t: int) -> Dic
     """compress_single_task return layout (reference compress.py:53-56); CPU tensors."""
     k, r = int(sm.k[p]), int(sm.r[p])
     return {"c_high_fp16": torch.from_numpy(sm.c_high[p, t, :k].copy()),
-            "c_low_quant": quant_payloads(sm, p, t, r - k, plan.bits, plan.S)}
+            "c_low_quant": quant_payloads(sm, p, t, r - k, plan.bits_of(p), plan.S)}
 
 
 class BatchResult:

@@ -112,7 +112,10 @@ def save_config(config, output_dir: str):
     """Reference storage.py:261-280."""
     os.makedirs(output_dir, exist_ok=True)
     with open(os.path.join(output_dir, "config.json"), "w") as f:
-        json.dump(asdict(config), f, indent=2)
+        d = asdict(config)
+        if callable(d.get("svd_low_bits_by_param")):      # a name -> bits function is not serialisable
+            d["svd_low_bits_by_param"] = None
+        json.dump(d, f, indent=2)
 
 
 def load_config(artifact_dir: str):

@@ -494,6 +494,43 @@ def test_combine_indices_equals_combine_then_indices(sq, strategy):
         assert torch.equal(it2[q][:n].long(), torch.nonzero(want).flatten())
 
 
+def test_mixed_code_widths_in_one_plan(sq, orc):
+    """BASELINE config #5 ("mixed 8-bit / 2-bit"): per-parameter widths inside one plan give, parameter by
+    parameter, exactly what single-width plans give; the driver partitions by name."""
+    from svdq_amd.pipeline import CompressPlan, task_artifact
+    dev = torch.device("cuda", 0)
+    N, sizes, widths = 20, [70001, 768, 30000, 5000], [8, 2, 8, 2]
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 390 + i)] for i, D in enumerate(sizes)]
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=True, rtvq_stages=2, device=dev)
+    mixed = CompressPlan(sizes, N, low_bits=widths, **kw)
+    mixed.run(mixed.pointer_table(vecs))
+    sm = mixed.fetch_small()
+    singles = {}
+    for b in (8, 2):
+        pl = CompressPlan(sizes, N, low_bits=b, **kw)
+        pl.run(pl.pointer_table(vecs))
+        singles[b] = pl.fetch_small()
+    for p, b in enumerate(widths):
+        ref = singles[b]
+        assert np.array_equal(sm.codes[p], ref.codes[p]) and np.array_equal(sm.scale[p], ref.scale[p])
+        assert np.array_equal(sm.zero_point[p], ref.zero_point[p]) and np.array_equal(sm.c_high[p], ref.c_high[p])
+        assert int(sm.codes[p].max()) <= (1 << b) - 1
+        assert task_artifact(mixed, sm, p, 0)["c_low_quant"]["num_bits"] == b
+    assert int(sm.codes[0].max()) > 3          # the 8-bit parameters really use more than 2 bits
+    with pytest.raises(ValueError, match="Low bits must be in"):
+        CompressPlan(sizes, N, low_bits=[8, 2, 9, 2], **kw)
+    # driver: partition by name
+    cfg = sq.SVDHybridConfig(svd_energy_threshold=0.9, svd_max_rank=None, svd_low_bits=4,
+                             svd_low_bits_by_param=lambda name: 8 if name.endswith("weight") else 2)
+    tv = {f"t{t:02d}": {"a.weight": vecs[0][t], "a.bias": vecs[1][t]} for t in range(N)}
+    bases, comp = sq.run_basis_and_compress(tv, {}, cfg, "cuda")
+    assert comp["a.weight"]["t00"]["masked"]["c_low_quant"]["num_bits"] == 8
+    assert comp["a.bias"]["t00"]["masked"]["c_low_quant"]["num_bits"] == 2
+    got = comp["a.bias"]["t03"]["masked"]["c_low_quant"]["payloads"][0]["quantized"].numpy()
+    nl = got.size
+    assert np.array_equal(got, singles[2].codes[1, 3, 0, :nl])
+
+
 # ------------------------------------------------------------------------------- masks
 def test_masks_vs_reference_vectors(sq):
     g = load_golden("masks.npz")
