@@ -33,6 +33,9 @@
 #ifndef SVDQ_UNROLL_BP
 #define SVDQ_UNROLL_BP 8
 #endif
+#ifndef SVDQ_UNROLL_BP2
+#define SVDQ_UNROLL_BP2 4  // sub-tile-pair loop of the two-wave pass 2 (N > 16)
+#endif
 #ifndef SVDQ_UNROLL_GRAM
 #define SVDQ_UNROLL_GRAM 8
 #endif
@@ -671,6 +674,254 @@ __global__ __launch_bounds__(64) void k_basis_project(
                                 meanbuf, cpart, idx_ptrs);
 }
 
+// ------------------------------------------------------------------------------------ N > 16: two waves
+// For 16 < N <= 32 the single-wave pass 2 needs 300+ registers (one wave per SIMD, nothing to overlap the
+// memory phases with).  This variant runs TWO wavefronts per workgroup on one shared LDS strip:
+//   * each wave loads and centres HALF of the tasks (half the prefetch registers); the row sums of the two
+//     halves meet in LDS (mean = (sum of wave 0's tasks + sum of wave 1's tasks) / N, in that order);
+//   * pass 2: wave w computes the 16-column block w of U (and of the rounding-correction MFMA), so the
+//     accumulator-side registers halve as well; both stage into the same output images.
+// (A two-wave pass 1 -- each wave the full 2x2-blocked Gram over half of the sub-tiles -- was measured 10 %
+// SLOWER than the single-wave k_gram at N = 20 and is not kept.)
+// Barriers are s_barrier after an LDS-only wait: a full __syncthreads() would also drain the prefetch.
+__device__ __forceinline__ void wg_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int HT, bool GATHER>
+__device__ __forceinline__ f32x4 center_store_half(const f32x4 (&v)[HT], int t0, int NT, int center, float *X,
+                                                   f32x4 *SUM, int wv, int lane) {
+    f32x4 s = zero4();
+#pragma unroll
+    for (int i = 0; i < HT; ++i) {
+        const f32x4 x = (t0 + i < NT) ? v[i] : zero4();
+        s += x;
+    }
+    SUM[wv * 64 + lane] = s;
+    wg_sync();
+    const f32x4 tot = SUM[lane] + SUM[64 + lane];
+    f32x4 mean = zero4();
+    if (center) {
+        const float n = (float)NT;
+        mean.x = tot.x / n;
+        mean.y = tot.y / n;
+        mean.z = tot.z / n;
+        mean.w = tot.w / n;
+    }
+#pragma unroll
+    for (int i = 0; i < HT; ++i) {
+        const f32x4 xc = (t0 + i < NT) ? (v[i] - mean) : zero4();
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) X[(t0 + i) * XS + 64 * e + lane] = xc[e];
+        } else {
+            *reinterpret_cast<f32x4 *>(X + (t0 + i) * XS + 4 * lane) = xc;
+        }
+    }
+    return mean;
+}
+
+// first block + one-block-ahead loads of one wave's HT tasks (contiguous or through the index list)
+template <int HT, bool GATHER>
+struct HalfLoader {
+    gfloat *bp[HT];
+    gint *gidx;
+    i32x4 ixn;
+    int64_t D, r_end;
+    int lane;
+    __device__ __forceinline__ void first(f32x4 (&v)[HT], int64_t r_begin) {
+        ixn = i32x4{-1, -1, -1, -1};
+        if (r_begin >= r_end) return;
+        if constexpr (GATHER) {
+            const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
+            load_block_gather<HT>(v, bp, ix0, r_begin + SVDQ_BLK_ROWS <= D);
+            if (r_begin + SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, r_begin + SVDQ_BLK_ROWS, D, lane);
+        } else {
+            load_block<HT>(v, bp, r_begin, D, lane);
+        }
+    }
+    __device__ __forceinline__ void next(f32x4 (&v)[HT], int64_t rb) {  // data of block rb + 256
+        if (rb + SVDQ_BLK_ROWS >= r_end) return;
+        if constexpr (GATHER) {
+            load_block_gather<HT>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
+            if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
+        } else {
+            load_block<HT>(v, bp, rb + SVDQ_BLK_ROWS, D, lane);
+        }
+    }
+};
+
+__device__ __forceinline__ void copy_out_wg(const void *lds_src, uint8_t *gdst, int nbytes, int tid) {
+    const int nvec = nbytes >> 4;
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(lds_src);
+    f32x4 *d4 = reinterpret_cast<f32x4 *>(gdst);
+    for (int i = tid; i < nvec; i += 128) d4[i] = s4[i];
+    const uint8_t *sb = reinterpret_cast<const uint8_t *>(lds_src);
+    for (int b = (nvec << 4) + 2 * tid; b < nbytes; b += 256)
+        *reinterpret_cast<uint16_t *>(gdst + b) = *reinterpret_cast<const uint16_t *>(sb + b);
+}
+
+template <int NTP, bool OUT16, bool GATHER>
+__global__ __launch_bounds__(128) void k_basis_project2(
+    const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
+    const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
+    const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
+    uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse,
+    const int32_t *const *__restrict__ idx_ptrs) {
+    static_assert(NTP > 16 && NTP <= 32 && NTP % 4 == 0, "two-wave variant is for 16 < N <= 32");
+    using out_t = typename OutT<OUT16>::type;
+    constexpr int HT = NTP / 2;
+    constexpr int KS = NTP / 4;
+    constexpr int ES = OUT16 ? 2 : 4;
+    __shared__ __attribute__((aligned(16))) float X[NTP * XS];
+    __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];
+    __shared__ __attribute__((aligned(16))) f32x4 SUM[128];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    const SvdqUnit ud = units[uidx];
+    const int p = ud.param;
+    const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
+    const int64_t r_begin = ud.row0;
+    int64_t r_end = r_begin + ud.nrows;
+    if (r_end > D) r_end = D;
+    const int k = k_dev[p], r = r_dev[p], nl = r - k;
+    const int t0 = wv * HT;
+
+    HalfLoader<HT, GATHER> ld;
+#pragma unroll
+    for (int i = 0; i < HT; ++i) ld.bp[i] = (gfloat *)ptrs[(size_t)p * NT + (t0 + i < NT ? t0 + i : NT - 1)];
+    ld.gidx = GATHER ? (gint *)idx_ptrs[p] : nullptr;
+    ld.D = D;
+    ld.r_end = r_end;
+    ld.lane = lane;
+
+    const int c = lane & 15, g = lane >> 4;
+    // this wave's 16-column block of W = V Sigma^-1: B-operand registers
+    const float *Wp = Wtab + (size_t)p * (NT * NT + 4);
+    const float spike = Wp[NT * NT];
+    const int nullcol = (int)Wp[NT * NT + 1];
+    const int icol = 16 * wv + c;  // the U column this lane owns
+    float w[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t = 4 * s + g;
+        w[s] = (t < NT && icol < NT) ? Wp[t * NT + icol] : 0.f;
+    }
+    out_t *const OUTh = OUT;
+    out_t *const OUTl = OUT + SVDQ_BLK_ROWS * k;
+    out_t *const DUMP = OUT + SVDQ_BLK_ROWS * NTP;
+    const bool cvalid = icol < r;
+    out_t *const colbase = !cvalid ? DUMP : (icol < k ? OUTh + icol : OUTl + (icol - k));
+    const int colstride = !cvalid ? 0 : (icol < k ? k : nl);
+
+    uint8_t *slab = basis + params[p].slab_off;
+    uint8_t *gUh = slab;
+    uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
+    float *gmean = (center && meanbuf) ? meanbuf + params[p].mean_off : nullptr;
+
+    double caccd[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) caccd[i][e] = 0.0;
+
+    // projection B operand ("task on slot, row on k") for the two 16-task blocks
+    const float *xb_ptr[2];
+    bool xb_ok[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int t = 16 * nb + c;
+        xb_ok[nb] = t < NTP;
+        xb_ptr[nb] = X + (xb_ok[nb] ? t : 0) * XS + 4 * g;
+    }
+
+    f32x4 v[HT];
+    ld.first(v, r_begin);
+    for (int64_t rb = r_begin; rb < r_end; rb += SVDQ_BLK_ROWS) {
+        const f32x4 mean = center_store_half<HT, GATHER>(v, t0, NT, center, X, SUM, wv, lane);
+        if (gmean && wv == 0) {
+            if constexpr (GATHER) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (rb + 64 * e + lane < D) gmean[rb + 64 * e + lane] = mean[e];
+            } else {
+                const int64_t rr = rb + 4 * lane;
+                if (rr + 3 < D) {
+                    *reinterpret_cast<f32x4 *>(gmean + rr) = mean;
+                } else {
+                    if (rr < D) gmean[rr] = mean.x;
+                    if (rr + 1 < D) gmean[rr + 1] = mean.y;
+                    if (rr + 2 < D) gmean[rr + 2] = mean.z;
+                }
+            }
+        }
+        wg_sync();
+        ld.next(v, rb);
+
+        f32x4 cf[2];
+        cf[0] = zero4();
+        cf[1] = zero4();
+UNROLL_N(SVDQ_UNROLL_BP2)
+        for (int jj = 0; jj < 8; ++jj) {
+            f32x4 err[2];
+            f32x4 xb[2][2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int j = 2 * jj + s2;
+                f32x4 u = zero4();
+#pragma unroll
+                for (int s = 0; s < KS; ++s) u = mfma4(X[(4 * s + g) * XS + 16 * j + c], w[s], u);
+                if (j == 0 && rb == 0 && g == 0 && icol == nullcol) u[0] += spike;  // completion column, row 0
+                out_t *dst = colbase + (16 * j + 4 * g) * colstride;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (OUT16) {
+                        const __half h = __float2half_rn(u[e]);
+                        dst[e * colstride] = h;
+                        err[s2][e] = __half2float(h) - u[e];
+                    } else {
+                        dst[e * colstride] = u[e];
+                    }
+                }
+                if constexpr (OUT16) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        xb[nb][s2] = *reinterpret_cast<const f32x4 *>(xb_ptr[nb] + 16 * j);
+                        if (!xb_ok[nb]) xb[nb][s2] = zero4();
+                    }
+                }
+            }
+            if constexpr (OUT16) {
+                const bf16x8 ea = pack_bf16(err[0], err[1]);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) cf[nb] = mfma_bf16(ea, pack_bf16(xb[nb][0], xb[nb][1]), cf[nb]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) caccd[i][e] += (double)cf[i][e];
+        wg_sync();
+
+        const int rows_blk = (int)((D - rb < SVDQ_BLK_ROWS) ? (D - rb) : SVDQ_BLK_ROWS);
+        if (k > 0) copy_out_wg(OUTh, gUh + rb * (int64_t)k * ES, rows_blk * k * ES, threadIdx.x);
+        if (nl > 0) copy_out_wg(OUTl, gUl + rb * (int64_t)nl * ES, rows_blk * nl * ES, threadIdx.x);
+        wg_sync();
+    }
+
+    // rounding-correction partials: cpart[unit][t*NT + i]; lane (c,g) holds D[m = U column 16 wv + 4g+e][n = task]
+    double *dst = cpart + (size_t)uidx * NT * NT;
+#pragma unroll
+    for (int nbt = 0; nbt < 2; ++nbt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 16 * wv + 4 * g + e;
+            const int t = 16 * nbt + c;
+            if (i < NT && t < NT) dst[t * NT + i] = caccd[nbt][e];
+        }
+}
+
 // ------------------------------------------------------------------------------------ fused schedule
 // One launch for gram -> eig/rank -> basis+projection (svdq_compress with the fused bit): every workgroup
 // (one wavefront) takes ONE item from a host-built queue through an atomic ticket.  The queue
@@ -839,10 +1090,9 @@ int svdq_launch_fused(const svdq_plan *pl, const void *ptrs, const int64_t *rows
         case 8: return launch_fused_t<8>(pl, a, st);
         case 12: return launch_fused_t<12>(pl, a, st);
         case 16: return launch_fused_t<16>(pl, a, st);
-        case 20: return launch_fused_t<20>(pl, a, st);
-        case 24: return launch_fused_t<24>(pl, a, st);
-        case 28: return launch_fused_t<28>(pl, a, st);
-        case 32: return launch_fused_t<32>(pl, a, st);
+        case 20: case 24: case 28: case 32:
+            svdq_set_error("the fused schedule is implemented for N <= 16 tasks");
+            return SVDQ_EUNSUPPORTED;
     }
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;
@@ -886,9 +1136,17 @@ static int launch_bp_t(const svdq_plan *pl, const void *ptrs, const int64_t *row
                        int unit0, int nunits, int reverse, const void *idx, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
     auto ip = reinterpret_cast<const int32_t *const *>(idx);
-#define SVDQ_LAUNCH_BP(F16, G)                                                                                   \
-    hipLaunchKernelGGL((k_basis_project<NTP, F16, G>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, \
-                       rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean, cpart, unit0, reverse, ip)
+#define SVDQ_LAUNCH_BP(F16, G)                                                                                        \
+    do {                                                                                                              \
+        if constexpr (NTP > 16)                                                                                       \
+            hipLaunchKernelGGL((k_basis_project2<NTP, F16, G>), dim3(nunits), dim3(128), 0, st, pl->d_params,         \
+                               pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
+                               cpart, unit0, reverse, ip);                                                            \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_basis_project<NTP, F16, G>), dim3(nunits), dim3(64), 0, st, pl->d_params,           \
+                               pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
+                               cpart, unit0, reverse, ip);                                                            \
+    } while (0)
     if (pl->cfg.fp16) {
         if (idx) SVDQ_LAUNCH_BP(true, true); else SVDQ_LAUNCH_BP(true, false);
     } else {

@@ -395,7 +395,7 @@ def test_pipelined_schedule_and_ranges_bit_identical(sq, orc):
     same_artifacts(rng)
 
 
-@pytest.mark.parametrize("N,fp16,lag_mb", [(8, True, 1), (8, True, 0), (3, False, 2), (16, True, 4), (20, True, 1)])
+@pytest.mark.parametrize("N,fp16,lag_mb", [(8, True, 1), (8, True, 0), (3, False, 2), (16, True, 4), (12, False, 1)])
 def test_fused_schedule_bit_identical(sq, orc, N, fp16, lag_mb):
     """svdq_compress with the fused bit (one launch for gram + eig + basis_project: atomic item queue, last-arriver
     reduction and eigen-stage, in-memory ready flags) produces exactly the artifacts of the four plain launches,
@@ -428,6 +428,15 @@ def test_fused_schedule_bit_identical(sq, orc, N, fp16, lag_mb):
             fus.run(tab, rd)
         torch.cuda.synchronize()
         assert torch.equal(fus.small, first)
+
+
+def test_fused_schedule_refuses_more_than_16_tasks(sq, orc):
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(5000, 20, 7)]]
+    plan = CompressPlan([5000], 20, flags=4, device=dev)
+    with pytest.raises(RuntimeError, match="N <= 16"):
+        plan.run(plan.pointer_table(vecs))
 
 
 @pytest.mark.parametrize("N,fp16,density", [(8, True, 0.94), (8, True, 0.2), (5, False, 0.6), (20, True, 0.9)])
