@@ -95,13 +95,14 @@ def compute_weights(task_names: List[str], weighting_strategy: str = "uniform",
 def apply_weights_to_tensors(tensors: Dict, weights: Dict, device: str = "cpu") -> torch.Tensor:
     """weighting.py:332-372: weighted average over sorted keys, weights renormalised to sum 1.
 
-    The tensors stay where they are when they already live on a GPU (``device="cpu"`` is the
-    reference's default argument, not a request to leave the accelerator)."""
+    Computed on the GPU like everything else in this package (``device="cpu"`` is the reference's default
+    argument; there is no CPU path here, and without a GPU this raises)."""
+    from .pipeline import resolve_device
     if not tensors:
         raise ValueError("Empty tensor dictionary")
     names = sorted(tensors.keys())
     first = tensors[names[0]]
-    dev = first.device if first.is_cuda else torch.device(device)
+    dev = first.device if first.is_cuda else resolve_device(device)
     stack = torch.stack([tensors[n].to(dev).float() for n in names], dim=0)
     w = torch.tensor([weights.get(n, 1.0 / len(names)) for n in names], device=dev, dtype=torch.float32)
     w = (w / w.sum()).view([len(names)] + [1] * (stack.dim() - 1))
