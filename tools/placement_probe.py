@@ -1,0 +1,49 @@
+"""Does the relative placement of the output buffers (basis, mean) against the task buffers change pass 2's
+speed?  bench.py shows k_basis_project at either ~2.75 or ~3.0 ms from one process to the next."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import svdq_amd
+from svdq_amd import workloads
+from svdq_amd.pipeline import CompressPlan
+
+dev = torch.device("cuda", 0)
+N = 8
+shapes = workloads.vit_visual_shapes("ViT-L-14")
+rows = [workloads.numel(shapes[k]) for k in sorted(shapes)]
+bufs, views = workloads.synth_task_buffers(rows, N, seed=1, device=dev)
+plan = CompressPlan(rows, N, energy_threshold=0.9, max_rank=64, center=True, fp16=True, device=dev)
+table = plan.pointer_table(views)
+plan.run(table); torch.cuda.synchronize()
+print("task buffers at", [hex(b.data_ptr()) for b in bufs], flush=True)
+print("basis", hex(plan.basis.data_ptr()), "mean", hex(plan.mean.data_ptr()), "ws", hex(plan.workspace.data_ptr()), flush=True)
+
+def timed(reps=10):
+    plan.basis_project(table); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        plan.basis_project(table)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+base_basis, base_mean = plan.basis, plan.mean
+print("as allocated:", round(timed(), 4), flush=True)
+MB = 1 << 20
+def tz(x):
+    return (x & -x).bit_length() - 1
+print("basis align 2^%d, mean 2^%d" % (tz(base_basis.data_ptr()), tz(base_mean.data_ptr())), flush=True)
+keep = []
+for extra in (0, 1, 2, 3, 64, 600, 1024, 2048, 0, 0):
+    big = torch.empty(base_basis.numel() + extra * MB, dtype=torch.uint8, device=dev)
+    keep.append(big)
+    plan.basis = big[:base_basis.numel()]
+    t1 = timed()
+    # first-touch / state effects: time again after the buffer has been fully written once by memset
+    big.zero_(); torch.cuda.synchronize()
+    t2 = timed()
+    print(f"new buffer +{extra:>5} MB at {hex(big.data_ptr())} (2^{tz(big.data_ptr())}): {t1:.4f}  after zero_: {t2:.4f}", flush=True)
+plan.basis = base_basis
+print("original again:", round(timed(), 4), flush=True)
+free, total = torch.cuda.mem_get_info()
+print("free GB", free / 2**30, "total", total / 2**30)
