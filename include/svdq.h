@@ -197,7 +197,8 @@ int64_t svdq_tvq_work_bytes(const svdq_plan *plan);
  * mode 0: asymmetric_quantization (quantization_utils.py:76-99) -> uint8 codes, scale, zero_point;
  * mode 1: absmax_quantization (quantization_utils.py:60-73)     -> int8 codes, scale.
  * As used by QuantizedFinetunedModel / QuantizedBaseAndTaskVector (task_vectors.py:764-1010).
- * scale / zero_point: device float [n_params * n_tasks].  bits in [1, 8] (absmax: [2, 8]). */
+ * scale / zero_point: device float [n_params * n_tasks].  bits in [1, 8] (absmax: [2, 8], or 16 -> int16 codes,
+ * code buffers then 8-byte aligned; dequantize those with mode 2). */
 int svdq_tvq_quantize(const svdq_plan *plan, const void *x_ptrs, int32_t mode, int32_t bits, const void *code_ptrs,
                       float *scale, float *zero_point, void *work, int32_t stats_ready, void *stream);
 

@@ -106,13 +106,13 @@ def asym_dequantize(q, scale, zp) -> np.ndarray:
 
 def absmax_quantize(x, bits: int = 8) -> Tuple[np.ndarray, np.float32]:
     """quantization_utils.py:60-73: s = (2^(b-1) - 1) / max|X| (python-int / Tensor = reciprocal * int, two
-    roundings), codes = round(s * X) as int8 (half-to-even; no clamp)."""
+    roundings), codes = round(s * X) as int8 (int16 for 16 bits; half-to-even; no clamp)."""
     xf = _f32(x)
     amax = np.float32(np.max(np.abs(xf)))
     with np.errstate(divide="ignore", invalid="ignore"):
         s = np.float32(np.float32(1.0) / amax) * np.float32(2 ** (bits - 1) - 1)
         q = np.rint((s * xf).astype(np.float32))
-    return q.astype(np.int8), np.float32(s)
+    return q.astype(np.int16 if bits == 16 else np.int8), np.float32(s)
 
 
 def absmax_dequantize(q, scale) -> np.ndarray:

@@ -40,6 +40,8 @@ from .task_vectors import TaskVector, QuantizedTaskVector, QuantizedFinetunedMod
 from .ingest import ElementwiseBatch, ingest_state_dicts, quantize_state_dict, dequantize_payloads
 from .driver import build_bases, run_basis_and_compress
 from .pipeline import CompressPlan, compress_batch
+from . import quantization_utils
+from .quantization_utils import absmax_quantization, dequantize_absmax
 from . import cli
 from . import torch_ops   # registers torch.ops.svdq.*
 

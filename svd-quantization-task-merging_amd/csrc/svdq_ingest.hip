@@ -188,6 +188,81 @@ __device__ __forceinline__ unsigned char tvq_code(float x, float scale, float zp
     return mode == 0 ? (unsigned char)vq : (unsigned char)(signed char)vq;
 }
 
+// absmax with qbit = 16: int16 codes (quantization_utils.py:67-70), no clamp in the reference -- the int16 range
+// only guards the cast
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ short tvq_code16(float x, float scale) {
+    float vq = rintf(__fmul_rn(scale, x));
+    if (vq != vq) return 0;
+    vq = vq < -32768.f ? -32768.f : (vq > 32767.f ? 32767.f : vq);
+    return (short)vq;
+}
+
+__global__ __launch_bounds__(64) void k_tvq_apply16(const SvdqParam *__restrict__ params,
+                                                    const SvdqUnit *__restrict__ units, int NT,
+                                                    const float *const *__restrict__ x_ptrs,
+                                                    const float *__restrict__ scale_in,
+                                                    short *const *__restrict__ code_ptrs) {
+    const int uidx = blockIdx.x, lane = threadIdx.x;
+    const SvdqUnit u = units[uidx];
+    const int p = u.param;
+    const int64_t D = params[p].rows;
+    const int64_t r0 = u.row0, r1 = r0 + u.nrows;
+    const int64_t v1 = (r1 == D) ? (D & ~(int64_t)3) : r1;
+    for (int t = 0; t < NT; ++t) {
+        const float *x = x_ptrs[(size_t)p * NT + t];
+        short *c = code_ptrs[(size_t)p * NT + t];
+        const float scale = scale_in[(size_t)p * NT + t];
+        for (int64_t i = r0 + 4 * lane; i < v1; i += 256) {
+            const f32x4 v = *AS1(f32x4, x + i);
+            i16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = tvq_code16(v[e], scale);
+            *reinterpret_cast<i16x4 *>(c + i) = o;
+        }
+        if (r1 == D && lane < (int)(D & 3)) c[v1 + lane] = tvq_code16(x[v1 + lane], scale);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tvq_dequant16(const SvdqParam *__restrict__ params,
+                                                      const SvdqUnit *__restrict__ units, int NT,
+                                                      const short *const *__restrict__ code_ptrs,
+                                                      const float *__restrict__ scale_in,
+                                                      const float *const *__restrict__ add_ptrs,
+                                                      float *const *__restrict__ out_ptrs) {
+    const int uidx = blockIdx.x, lane = threadIdx.x;
+    const SvdqUnit u = units[uidx];
+    const int p = u.param;
+    const int64_t D = params[p].rows;
+    const int64_t r0 = u.row0, r1 = r0 + u.nrows;
+    const int64_t v1 = (r1 == D) ? (D & ~(int64_t)3) : r1;
+    const float *add = add_ptrs ? add_ptrs[p] : nullptr;
+    for (int t = 0; t < NT; ++t) {
+        const short *c = code_ptrs[(size_t)p * NT + t];
+        float *o = out_ptrs[(size_t)p * NT + t];
+        const float scale = scale_in[(size_t)p * NT + t];
+        for (int64_t i = r0 + 4 * lane; i < v1; i += 256) {
+            const i16x4 q = *AS1(i16x4, c + i);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __fmul_rn((float)q[e], scale);
+            if (add) {
+                const f32x4 a = *AS1(f32x4, add + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(a[e], v[e]);
+            }
+            *reinterpret_cast<f32x4 *>(o + i) = v;
+        }
+        if (r1 == D && lane < (int)(D & 3)) {
+            const int64_t i = v1 + lane;
+            float v = __fmul_rn((float)c[i], scale);
+            if (add) v = __fadd_rn(add[i], v);
+            o[i] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_tvq_apply(const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
                                                   int NT, int mode, int bits, const float *const *__restrict__ x_ptrs,
                                                   const float *__restrict__ scale_in, const float *__restrict__ zp_in,
@@ -306,8 +381,10 @@ static int tvq_check(const svdq_plan *pl, int32_t mode, int32_t bits) {
         svdq_set_error("Unknown quantization method %d (0 = asymmetric, 1 = absmax)", mode);
         return SVDQ_EINVAL;
     }
+    if (mode == 1 && bits == 16) return SVDQ_OK;  // int16 codes
     if (bits < 1 || bits > 8 || (mode == 1 && bits < 2)) {
-        svdq_set_error("qbit must be in [%d, 8], got %d (int16 codes are not implemented)", mode == 1 ? 2 : 1, bits);
+        svdq_set_error("qbit must be in [%d, 8]%s, got %d (asymmetric int16 codes are not implemented)",
+                       mode == 1 ? 2 : 1, mode == 1 ? " or 16" : "", bits);
         return SVDQ_EUNSUPPORTED;
     }
     return SVDQ_OK;
@@ -348,14 +425,28 @@ extern "C" int svdq_tvq_quantize(const svdq_plan *pl, const void *x_ptrs, int32_
     const int nt = pl->n_params * pl->n_tasks;
     hipLaunchKernelGGL(k_tvq_params, dim3((nt + 63) / 64), dim3(64), 0, st, pl->d_params, pl->n_params, pl->n_tasks, mode,
                        bits, part, scale, zero_point);
-    hipLaunchKernelGGL(k_tvq_apply, dim3(pl->n_units), dim3(64), 0, st, pl->d_params, pl->d_units, pl->n_tasks, mode, bits,
-                       xp, scale, zero_point, reinterpret_cast<uint8_t *const *>(code_ptrs));
+    if (bits == 16)
+        hipLaunchKernelGGL(k_tvq_apply16, dim3(pl->n_units), dim3(64), 0, st, pl->d_params, pl->d_units, pl->n_tasks, xp,
+                           scale, reinterpret_cast<short *const *>(code_ptrs));
+    else
+        hipLaunchKernelGGL(k_tvq_apply, dim3(pl->n_units), dim3(64), 0, st, pl->d_params, pl->d_units, pl->n_tasks, mode,
+                           bits, xp, scale, zero_point, reinterpret_cast<uint8_t *const *>(code_ptrs));
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
 extern "C" int svdq_tvq_dequantize(const svdq_plan *pl, const void *code_ptrs, int32_t mode, const float *scale,
                                    const float *zero_point, const void *add_ptrs, const void *out_ptrs,
                                    void *stream) {
+    if (mode == 2) {  // absmax with int16 codes
+        if (!pl || !code_ptrs || !scale || !out_ptrs) {
+            svdq_set_error("null argument");
+            return SVDQ_EINVAL;
+        }
+        hipLaunchKernelGGL(k_tvq_dequant16, dim3(pl->n_units), dim3(64), 0, (hipStream_t)stream, pl->d_params,
+                           pl->d_units, pl->n_tasks, reinterpret_cast<const short *const *>(code_ptrs), scale,
+                           reinterpret_cast<const float *const *>(add_ptrs), reinterpret_cast<float *const *>(out_ptrs));
+        return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+    }
     if (int rc = tvq_check(pl, mode, 8)) return rc;
     if (!code_ptrs || !scale || !out_ptrs || (mode == 0 && !zero_point)) {
         svdq_set_error("null argument");

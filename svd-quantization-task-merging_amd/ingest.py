@@ -59,7 +59,7 @@ class ElementwiseBatch:
                  ) -> Tuple[List[torch.Tensor], torch.Tensor, Optional[torch.Tensor]]:
         dev, mode = self.dev, _method_id(method)
         with torch.cuda.device(dev):
-            cdt = torch.uint8 if mode == 0 else torch.int8
+            cdt = torch.uint8 if mode == 0 else (torch.int16 if int(bits) == 16 else torch.int8)
             codes = [torch.empty(self.rows[i // self.N], dtype=cdt, device=dev) for i in range(self.P * self.N)]
             scale = torch.empty(self.P * self.N, dtype=torch.float32, device=dev)
             zp = torch.empty(self.P * self.N, dtype=torch.float32, device=dev) if mode == 0 else None
@@ -72,6 +72,8 @@ class ElementwiseBatch:
     def dequantize(self, codes: Sequence[torch.Tensor], scale: torch.Tensor, zp: Optional[torch.Tensor], method: str,
                    add: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
         dev, mode = self.dev, _method_id(method)
+        if mode == 1 and codes and codes[0].dtype == torch.int16:
+            mode = 2          # absmax with int16 codes (qbit = 16)
         with torch.cuda.device(dev):
             outs = [torch.empty(self.rows[i // self.N], dtype=torch.float32, device=dev) for i in range(self.P * self.N)]
             tc, to = _table(codes, dev), _table(outs, dev)
@@ -83,7 +85,7 @@ class ElementwiseBatch:
 
 
 def _codes_flat(q: torch.Tensor, dev: torch.device, mode: int) -> torch.Tensor:
-    want = torch.uint8 if mode == 0 else torch.int8
+    want = torch.uint8 if mode == 0 else (torch.int16 if q.dtype == torch.int16 else torch.int8)
     c = q.detach().to(device=dev)
     if c.dtype != want:
         c = c.to(want)
@@ -148,8 +150,8 @@ def quantize_state_dict(state: Dict[str, torch.Tensor], qbit: int = 8, method: s
     (the per-parameter loop of QuantizedFinetunedModel.__init__, task_vectors.py:764-845)."""
     dev = resolve_device(device)
     mode = _method_id(method)
-    if not (1 <= int(qbit) <= 8) or (mode == 1 and int(qbit) < 2):
-        raise NotImplementedError(f"qbit={qbit}: only 8-bit-or-narrower codes are implemented (int16 is not)")
+    if not ((1 <= int(qbit) <= 8 and not (mode == 1 and int(qbit) < 2)) or (mode == 1 and int(qbit) == 16)):
+        raise NotImplementedError(f"qbit={qbit}: codes of 8 bits or fewer (and int16 for absmax) are implemented")
     keys = []
     for k, v in state.items():
         if not isinstance(v, torch.Tensor):
@@ -193,8 +195,9 @@ def dequantize_payloads(payloads: Dict[str, Dict], method: str = "asymmetric", d
     if not keys:
         return {}
     out: Dict[str, torch.Tensor] = {}
-    for with_add in (False, True):
-        sel = [k for k in keys if ((add is not None and k in add) == with_add) and payloads[k]["quantized"].numel() > 0]
+    for with_add, wide in ((False, False), (True, False), (False, True), (True, True)):
+        sel = [k for k in keys if ((add is not None and k in add) == with_add) and payloads[k]["quantized"].numel() > 0
+               and (payloads[k]["quantized"].dtype == torch.int16) == wide]
         if not sel:
             continue
         with torch.cuda.device(dev):

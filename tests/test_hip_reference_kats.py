@@ -1,0 +1,144 @@
+"""
+The reference's own unit tests for task vectors and quantization_utils (tests/test_task_vectors.py,
+tests/test_quantization_utils.py of mgradyn/SVD-Quantization-Task-Merging), re-expressed against this package:
+same scenarios and thresholds, tensors on the GPU.  They need no oracle -- the expected values are stated in
+the reference's tests themselves.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import svd_hybrid_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sq():
+    import svdq_amd
+    return svdq_amd
+
+
+def _pair(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    pre = {"layer1.weight": torch.randn(10, 5, generator=g), "layer1.bias": torch.randn(10, generator=g),
+           "layer2.weight": torch.randn(3, 10, generator=g), "layer2.bias": torch.randn(3, generator=g)}
+    fin = {k: v + 0.1 * torch.randn(v.shape, generator=g) for k, v in pre.items()}
+    return pre, fin
+
+
+def test_task_vector_creation_and_delta(sq):                      # test_task_vectors.py:27-60
+    pre, fin = _pair()
+    tv = sq.TaskVector(pre, fin, verbose=False)
+    assert set(tv.vector) == set(pre)
+    for k in pre:
+        assert tv.vector[k].shape == pre[k].shape
+        assert torch.allclose(tv.vector[k].cpu(), fin[k] - pre[k])
+
+
+def test_task_vector_arithmetic_and_apply(sq):                     # :63-119
+    pre = {"weight": torch.ones(5, 5)}
+    tv1 = sq.TaskVector(pre, {"weight": torch.ones(5, 5) * 2}, task_name="a", verbose=False)
+    tv2 = sq.TaskVector(pre, {"weight": torch.ones(5, 5) * 3}, task_name="b", verbose=False)
+    assert torch.allclose((tv1 + tv2).vector["weight"].cpu(), torch.ones(5, 5) * 3)
+    assert torch.allclose((tv2 - tv1).vector["weight"].cpu(), torch.ones(5, 5))
+    assert torch.allclose((tv1 * 0.5).vector["weight"].cpu(), torch.ones(5, 5) * 0.5)
+    assert torch.allclose((2.0 * tv1).vector["weight"].cpu(), torch.ones(5, 5) * 2)
+    assert (tv1 + tv2).task_name == "a+b" and (tv2 - tv1).task_name == "b-a"
+    pre2, fin2 = _pair(3)
+    res = sq.TaskVector(pre2, fin2, verbose=False).apply_to(pre2)
+    for k in pre2:
+        assert torch.allclose(res[k].cpu(), fin2[k], atol=1e-6)
+
+
+@pytest.mark.parametrize("method", ["asymmetric", "absmax"])
+def test_quantized_models_reconstruct(sq, method):                  # :123-188
+    g = torch.Generator().manual_seed(5)
+    pre = {"weight": torch.randn(10, 5, generator=g), "bias": torch.randn(10, generator=g)}
+    fin = {k: v + 0.1 * torch.randn(v.shape, generator=g) for k, v in pre.items()}
+    qf = sq.QuantizedFinetunedModel(fin, qbit=8, method=method)
+    rec = qf.dequantize()
+    assert set(rec) == set(fin)
+    for k in fin:
+        assert rec[k].shape == fin[k].shape
+        if method == "asymmetric":      # absmax "dequantization" multiplies by the scale in the reference as well
+            assert float((rec[k].cpu() - fin[k]).norm() / fin[k].norm()) < 0.1
+    if method == "asymmetric":
+        tv = qf.get_task_vector(pre)
+        for k in pre:
+            true = fin[k] - pre[k]
+            assert float((tv[k].cpu() - true).norm() / true.norm()) < 0.2
+        vec = sq.TaskVector(pre, fin, verbose=False)
+        qb = sq.QuantizedBaseAndTaskVector(pre, vec, base_qbit=8, task_qbit=8, method=method)
+        rec2 = qb.dequantize()
+        assert set(rec2) == set(fin)
+        for k in fin:
+            assert float((rec2[k].cpu() - fin[k]).norm() / fin[k].norm()) < 0.2
+
+
+def test_task_vector_skips_integer_buffers_and_reads_files(sq, tmp_path):   # :191-227
+    pre = {"weight": torch.randn(5, 5), "buffer": torch.tensor([1, 2, 3], dtype=torch.int64)}
+    fin = {"weight": pre["weight"] + 0.5, "buffer": torch.tensor([4, 5, 6], dtype=torch.int64)}
+    tv = sq.TaskVector(pre, fin, verbose=False)
+    assert "weight" in tv.vector and "buffer" not in tv.vector
+    torch.save(pre, tmp_path / "pre.pt")
+    torch.save(fin, tmp_path / "fin.pt")
+    tv2 = sq.TaskVector(str(tmp_path / "pre.pt"), str(tmp_path / "fin.pt"), verbose=False)
+    assert torch.allclose(tv2.vector["weight"].cpu(), fin["weight"] - pre["weight"])
+
+
+def test_task_vector_from_model_objects(sq):                        # :230-295 and :355-426
+    class Visual(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(3, 8, kernel_size=3)
+            self.ln_pre = torch.nn.LayerNorm(8)
+            self.proj = torch.nn.Linear(8, 16)
+
+    class Clip(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.visual = Visual()
+            self.logit_scale = torch.nn.Parameter(torch.ones([]))
+
+    class Encoder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = Clip()
+
+    pre, fin = Encoder(), Encoder()
+    fin.load_state_dict(pre.state_dict())
+    with torch.no_grad():
+        for prm in fin.parameters():
+            prm.add_(0.01)
+    tv = sq.TaskVector(pre, fin, verbose=False)
+    assert any("model.visual" in k for k in tv.vector)
+    for k, d in tv.vector.items():
+        assert torch.allclose(d.cpu(), torch.full(d.shape, 0.01), atol=1e-6), k
+    res = tv.apply_to(pre)
+    for k in tv.vector:
+        assert torch.allclose(res[k].cpu(), fin.state_dict()[k], atol=1e-6), k
+
+
+def test_quantization_utils_absmax(sq):                             # test_quantization_utils.py:15-71
+    qu = sq.quantization_utils
+    torch.manual_seed(0)
+    X = torch.randn(100)
+    q8, s8 = qu.absmax_quantization(X, qbit=8)
+    assert q8.dtype == torch.int8 and isinstance(s8, torch.Tensor) and q8.shape == X.shape
+    assert int(q8.min()) >= -128 and int(q8.max()) <= 127
+    q16, s16 = qu.absmax_quantization(X, qbit=16)
+    assert q16.dtype == torch.int16 and int(q16.min()) >= -32768 and int(q16.max()) <= 32767
+    # bit-exact against the restated algorithm
+    for q, s_, b in ((q8, s8, 8), (q16, s16, 16)):
+        oq, os_ = orc.absmax_quantize(X.numpy(), b)
+        assert np.array_equal(q.cpu().numpy(), oq) and float(s_) == float(os_)
+        rec = qu.dequantize_absmax(q, s_)
+        assert rec.shape == X.shape
+        assert np.array_equal(rec.cpu().numpy(), orc.absmax_dequantize(oq, os_))
+    qa, sa, za = qu.asymmetric_quantization(X, qbit=8)
+    assert qa.dtype == torch.uint8
+    rec = qu.dequantize_asymmetric(qa, sa, za)
+    assert float((rec.cpu() - X).abs().max()) <= 0.5 / float(sa) * (1 + 1e-5)
+    with pytest.raises(NotImplementedError):
+        qu.asymmetric_quantization(X, qbit=16)
