@@ -98,11 +98,22 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("SVDQ_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(names, rows, n_tasks, args):
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(names, rows, n_tasks, args, threads=None, seconds=None):
     """The oracle (torch-CPU restatement of the reference op sequence) on a bounded sample of the
-    same workload: whole transformer blocks, as many as fit in ~args.cpu_seconds."""
+    same workload: whole transformer blocks, as many as fit in ~seconds."""
     from oracle import svd_hybrid_oracle as orc
-    threads = usable_cores()
+    threads = threads or usable_cores()
+    seconds = seconds if seconds is not None else args.cpu_seconds
     torch.set_num_threads(threads)
     # sample = leading resblocks (12 tensors each) + the global tensors
     blocks = {}
@@ -123,9 +134,10 @@ def cpu_baseline(names, rows, n_tasks, args):
             scalars += rows[i] * n_tasks
             del deltas
         sample_desc.append(bk)
-        if spent >= args.cpu_seconds:
+        if spent >= seconds:
             break
     return {"value": round(scalars / spent / 1e6, 2), "unit": "MParams/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": f"{args.model} x {n_tasks} tasks: tensors of [{', '.join(sample_desc[:2])}"
                       f"{' ...' if len(sample_desc) > 2 else ''}] = {len(sample_desc) - 1} resblocks + globals, "
                       f"{scalars / 1e6:.1f} M scalars in {spent:.1f} s (oracle: torch-CPU stack/mean/gesdd/project + C quantizer)"}
@@ -299,6 +311,16 @@ def main():
 
     sm = plan.fetch_small()
     k_mean = float(sm.k.mean())
+    # also the time to "small artifacts on the host" (one D2H of the packed buffer per step, which
+    # synchronises the stream); never the headline value
+    d2h_ms = None
+    if world == 1:
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(3):
+            step()
+            plan.fetch_small()
+        d2h_ms = (time.perf_counter() - t2) / 3 * 1e3
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -334,10 +356,17 @@ def main():
                               "unit": "GB/s", "frac": round(gram_bytes / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "algorithmic_bytes": int(gram_bytes)},
             "path_roofline_frac": round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "ms_per_step_incl_small_d2h": round(d2h_ms, 4) if d2h_ms is not None else None,
         }
         if not args.no_cpu and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline([names[i] for i in mine], rows, N, args)
+                if out["cpu_baseline"]["cores"] > 8:      # also at 8 threads, on a shorter sample;
+                    ball = out["cpu_baseline"]            # the faster of the two is the baseline we quote
+                    b8 = cpu_baseline([names[i] for i in mine], rows, N, args, threads=8, seconds=args.cpu_seconds / 2)
+                    best, other = (b8, ball) if b8["value"] > ball["value"] else (ball, b8)
+                    best["other_thread_count"] = {"cores": other["cores"], "value": other["value"]}
+                    out["cpu_baseline"] = best
             except Exception as e:  # the checker must never sink the measurement
                 out["cpu_baseline"] = {"value": None, "error": str(e)[:200]}
         print(json.dumps(out), flush=True)
