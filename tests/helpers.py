@@ -18,7 +18,7 @@ def bits_equal(a, b):
     b = np.ascontiguousarray(b)
     if a.shape != b.shape or a.dtype != b.dtype:
         return False
-    w = {2: np.uint16, 4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    w = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
     av, bv = a.view(w), b.view(w)
     if np.array_equal(av, bv):
         return True

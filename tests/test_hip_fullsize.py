@@ -107,3 +107,50 @@ def test_full_model(model, n_tasks, bits, stages, thr):
     torch.cuda.synchronize()
     assert torch.equal(plan.small, small1)
     assert torch.equal(plan.basis.view(torch.int16)[:: 4099], basis_sum1)
+
+
+def test_full_model_masked_union_gather():
+    """BASELINE configs[2] at full size: ViT-B-16 x 8 tasks, union of 8 synthetic masks (rand > 0.7), 4-bit x
+    4-stage, through combine -> index lists -> gather-mode stages.  The mask union and the selections are checked
+    against torch's own boolean ops, and for selected tensors the artifacts must equal, bit for bit, those of a
+    plain run on `x[mask]`."""
+    import svdq_amd  # noqa: F401
+    from svdq_amd import workloads
+    from svdq_amd.mask_loader import MaskSet
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    N = 8
+    shapes = workloads.vit_visual_shapes("ViT-B-16")
+    names = sorted(shapes)
+    rows = [workloads.numel(shapes[n]) for n in names]
+    bufs, views = workloads.synth_task_buffers(rows, N, seed=11, device=dev)
+    gm = torch.Generator(device=dev).manual_seed(5)
+    per_task = [[torch.rand(r, device=dev, generator=gm) > 0.7 for _ in range(N)] for r in rows]
+    ms = MaskSet(rows, dev)
+    outs, it, _, ct, _ = ms.prepare_combine_indices(per_task, "union", want_false=False)
+    ms.run_combine_indices()
+    kw = dict(energy_threshold=0.95, max_rank=64, center=True, fp16=True, low_bits=4, rtvq_stages=4, device=dev)
+    plan = CompressPlan(rows, N, **kw)
+    itab = torch.tensor([x.data_ptr() for x in it], dtype=torch.int64).to(dev)
+    plan.run_gather(plan.pointer_table(views), itab, ct)
+    sm = plan.fetch_small()
+    counts = ct.cpu().numpy()
+    assert np.array_equal(sm.rows, counts)
+    dens = counts.sum() / float(sum(rows))
+    assert 0.93 < dens < 0.95                                    # 1 - 0.7^8 = 0.942
+    assert np.isfinite(sm.sigma).all() and np.isfinite(sm.coef).all() and sm.k.min() >= 1
+    for want in ("transformer.resblocks.5.mlp.c_proj.weight", "positional_embedding", "ln_post.bias", "conv1.weight"):
+        p = names.index(want)
+        union = torch.stack(per_task[p]).any(dim=0)
+        assert torch.equal(outs[p].view(torch.bool), union) and int(union.sum()) == int(counts[p])
+        sel = [v[union].contiguous() for v in views[p]]          # torch's own boolean-index compaction
+        ref = CompressPlan([sel[0].numel()], N, **kw)
+        ref.run(ref.pointer_table([sel]))
+        sr = ref.fetch_small()
+        k, r, D = int(sr.k[0]), int(sr.r[0]), int(sr.rows[0])
+        assert (k, r, D) == (int(sm.k[p]), int(sm.r[p]), int(sm.rows[p]))
+        for field in ("sigma", "c_high", "codes", "scale", "zero_point", "coef"):
+            assert bits_equal(getattr(sm, field)[p], getattr(sr, field)[0]), (want, field)
+        a = plan.basis_tensors(p, k, r, D)
+        b = ref.basis_tensors(0, k, r, D)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
