@@ -113,18 +113,26 @@ def compress_all_parameters(task_vectors: Dict[str, Dict[str, torch.Tensor]], ma
                             bases: Dict[str, Dict], config, device: str = "cpu") -> Dict[str, Dict]:
     """Reference compress.py:173-207.  Parameters in sorted order, tasks in insertion order, one
     quantizer (b, S) for the whole run."""
+    import gc
     from .driver import artifacts_from_batch
     quantizer = RTVQQuantizer(num_bits=config.svd_low_bits, num_stages=config.svd_rtvq_stages)
     out = {}
-    for name in sorted(bases.keys()):
-        basis = bases[name]
-        fused = artifacts_from_batch(name, basis, task_vectors, config)
-        if fused is not None:
-            out[name] = fused
-            continue
-        comp = compress_parameter(name, task_vectors, masks.get(name), basis, quantizer,
-                                  include_noise=config.svd_include_noise, min_mask_size=config.svd_min_mask_size,
-                                  device=device)
-        if comp is not None:
-            out[name] = comp
+    # assembling ~10^4 small dictionaries and tensors: keep the cyclic collector from re-walking them all
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        for name in sorted(bases.keys()):
+            basis = bases[name]
+            fused = artifacts_from_batch(name, basis, task_vectors, config)
+            if fused is not None:
+                out[name] = fused
+                continue
+            comp = compress_parameter(name, task_vectors, masks.get(name), basis, quantizer,
+                                      include_noise=config.svd_include_noise,
+                                      min_mask_size=config.svd_min_mask_size, device=device)
+            if comp is not None:
+                out[name] = comp
+    finally:
+        if gc_was_on:
+            gc.enable()
     return out

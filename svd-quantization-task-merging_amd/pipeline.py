@@ -251,17 +251,42 @@ class CompressPlan:
 
 
 # ------------------------------------------------------------------------------------------------
+class _HostViews:
+    """torch views of the host copy of the small artifacts, split ONCE into per-row tuples: assembling the
+    reference's nested payload dictionaries for a ViT-L model touches ~10^4 scalars and rows, and one
+    torch.tensor() / indexing call per item costs more than the GPU work of the whole model."""
+
+    def __init__(self, sm: SmallArtifacts):
+        P, N, S = sm.scale.shape
+        self.N, self.S = N, S
+        self.scale = torch.from_numpy(np.ascontiguousarray(sm.scale)).reshape(-1).unbind(0)
+        self.zero_point = torch.from_numpy(np.ascontiguousarray(sm.zero_point)).reshape(-1).unbind(0)
+        self.rnorm = np.ascontiguousarray(sm.residual_norm).reshape(-1).tolist()
+        self.codes = torch.from_numpy(np.ascontiguousarray(sm.codes)).reshape(P * N * S, N).unbind(0)
+        self.c_high = torch.from_numpy(np.ascontiguousarray(sm.c_high)).reshape(P * N, N).unbind(0)
+
+
+def _views(sm: SmallArtifacts) -> _HostViews:
+    hv = getattr(sm, "_host_views", None)
+    if hv is None:
+        hv = _HostViews(sm)
+        sm._host_views = hv
+    return hv
+
+
 def quant_payloads(sm: SmallArtifacts, p: int, t: int, nl: int, bits: int, stages: int) -> Dict:
     """RTVQQuantizer.quantize output layout (reference rtvq.py:111-126, payloads rtvq.py:69-75)."""
     payloads = []
     if nl > 0:
+        hv = _views(sm)
+        base = (p * hv.N + t) * hv.S
         for s in range(stages):
             payloads.append({
                 "stage": s,
-                "quantized": torch.from_numpy(sm.codes[p, t, s, :nl].copy()),
-                "scale": torch.tensor(sm.scale[p, t, s]),
-                "zero_point": torch.tensor(sm.zero_point[p, t, s]),
-                "residual_norm": float(sm.residual_norm[p, t, s]),
+                "quantized": hv.codes[base + s][:nl],
+                "scale": hv.scale[base + s],
+                "zero_point": hv.zero_point[base + s],
+                "residual_norm": hv.rnorm[base + s],
             })
     return {"payloads": payloads, "num_bits": bits, "num_stages": stages,
             "original_shape": torch.Size([nl]), "original_dtype": "torch.float32"}
@@ -279,7 +304,7 @@ def basis_dict(plan: CompressPlan, sm: SmallArtifacts, p: int) -> Dict:
 def task_artifact(plan: CompressPlan, sm: SmallArtifacts, p: int, t: int) -> Dict:
     """compress_single_task return layout (reference compress.py:53-56); CPU tensors."""
     k, r = int(sm.k[p]), int(sm.r[p])
-    return {"c_high_fp16": torch.from_numpy(sm.c_high[p, t, :k].copy()),
+    return {"c_high_fp16": _views(sm).c_high[p * plan.N + t][:k],
             "c_low_quant": quant_payloads(sm, p, t, r - k, plan.bits_of(p), plan.S)}
 
 

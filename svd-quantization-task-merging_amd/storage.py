@@ -28,6 +28,18 @@ def _safe(name: str) -> str:
     return name.replace("/", "_").replace("\\", "_")
 
 
+def _compact(obj):
+    """Deep copy in which every tensor owns exactly its own elements: the payload tensors handed out by the
+    batched path are views into one packed host buffer, and torch.save writes a view's WHOLE storage."""
+    if isinstance(obj, torch.Tensor):
+        return obj.detach().cpu().clone()
+    if isinstance(obj, dict):
+        return {k: _compact(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)) and not isinstance(obj, torch.Size):
+        return type(obj)(_compact(v) for v in obj)
+    return obj
+
+
 def _basis_payload(b: Dict) -> Dict:
     return {"U_high": b["U_high"].cpu(), "U_low": b["U_low"].cpu(), "singular_values": b["singular_values"].cpu(),
             "k": b["k"], "mean": b["mean"].cpu() if b["mean"] is not None else None,
@@ -64,8 +76,8 @@ def save_compressed_coefficients(compressed: Dict[str, Dict[str, Dict]], output_
             a = {}
             for region in ("masked", "unmasked"):
                 if art.get(region) is not None:
-                    a[region] = {"c_high_fp16": art[region]["c_high_fp16"].cpu(),
-                                 "c_low_quant": art[region]["c_low_quant"]}
+                    a[region] = {"c_high_fp16": _compact(art[region]["c_high_fp16"]),
+                                 "c_low_quant": _compact(art[region]["c_low_quant"])}
             out[task] = a
         torch.save(out, os.path.join(d, f"{_safe(name)}.pt"))
 

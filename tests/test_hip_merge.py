@@ -160,6 +160,9 @@ def test_artifacts_reload_end_to_end(sq, tmp_path):
     diag["task_weights"] = weights
     d = str(tmp_path / "art")
     sq.save_all_artifacts(bases, comp, diag, cfg, d)
+    import os
+    for fn in os.listdir(os.path.join(d, "coeffs")):      # payload tensors are views of one packed host buffer:
+        assert os.path.getsize(os.path.join(d, "coeffs", fn)) < 32 * 1024, fn   # files hold only their own bytes
     base = {n: torch.randn(s).cuda() for n, s in shapes.items()}
     out_path = str(tmp_path / "merged.pt")
     res = sq.reconstruct_from_artifacts(d, base, out_path, device="cuda")
