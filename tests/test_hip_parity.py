@@ -296,6 +296,35 @@ def test_config1_plumbing(sq):
     assert torch.isnan(deq).all()
 
 
+def test_single_task_and_all_zero_inputs(sq, orc):
+    """N = 1 (T is one column) and all-zero deltas: the degenerate ends of the pipeline."""
+    dev = torch.device("cuda", 0)
+    x = orc.synthetic_deltas(30001, 1, 77)[0]
+    for center in (False, True):
+        ref = orc.compress_parameter([x], 0.9, 64, center, True, 4, 2)
+        plan, sm = sq.compress_batch([[x.to(dev)]], energy_threshold=0.9, max_rank=64, center=center, fp16=True,
+                                     low_bits=4, rtvq_stages=2, device=dev)
+        k, r = int(sm.k[0]), int(sm.r[0])
+        assert (k, r) == (1, 1) == (ref["basis"]["k"], 1)
+        recon = _reconstruct_all(sq, plan, sm, 0, 1)[0]
+        if center:      # Tc = 0: everything is in the mean
+            assert np.array_equal(recon, x.numpy())
+            assert float(sm.sigma[0, 0]) == 0.0
+        else:
+            np.testing.assert_allclose(sm.sigma[0, 0], float(x.norm()), rtol=2e-6)
+            assert float(np.mean((recon - ref["recon"][0].numpy()) ** 2)) <= MSE_TOL
+            assert np.linalg.norm(recon - x.numpy()) / float(x.norm()) < 2e-3      # fp16 basis and coefficient
+    # all-zero deltas: sigma = 0, the energy rule's "all ones" branch (basis.py:147-150), k = 1, zero basis
+    z = [torch.zeros(5000, device=dev) for _ in range(4)]
+    plan, sm = sq.compress_batch([z], energy_threshold=0.9, max_rank=64, center=True, fp16=True, low_bits=4,
+                                 rtvq_stages=2, device=dev)
+    k_ref = orc.select_rank(torch.zeros(4), 0.9, 64)
+    assert int(sm.k[0]) == k_ref and np.all(sm.sigma[0] == 0.0)
+    U_high, U_low, mean = plan.basis_tensors(0, int(sm.k[0]), int(sm.r[0]), 5000)
+    assert float(U_high.abs().max()) <= 1.0 and float(mean.abs().max()) == 0.0
+    assert torch.isfinite(U_high.float()).all() and torch.isfinite(U_low.float()).all()
+
+
 # ------------------------------------------------------------------------------- oracle at larger sizes
 @pytest.mark.parametrize("D,N,seed,thr,bits,stages", [
     (589824, 8, 31, 0.90, 4, 2),       # one ViT-B 768x768 matrix
