@@ -205,7 +205,11 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     static_assert(!(GATHER && SVDQ_PREFETCH2), "gather mode supports the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
-    constexpr int NACC = (NB == 1) ? 1 : 3;  // AA | AA, AB, BB
+    // N = 17..20: the BB block of the 2x2-blocked Gram is only 4 x 4.  A 16x16x4 MFMA per k-step for it wastes 15/16
+    // of the matrix pipe, and pass 1 at N = 20 is MFMA-issue-bound (SQ_WAIT_INST_ANY 69 %, MFMA busy 58 %): the ten
+    // products of tasks 16..19 are taken on the vector ALU from the registers the centred rows are still in.
+    constexpr bool VBB = (NTP == 20);
+    constexpr int NACC = (NB == 1) ? 1 : (VBB ? 2 : 3);  // AA | AA, AB, BB
 
     const int lane = threadIdx.x & 63;
     const SvdqUnit ud = units[uidx];
@@ -225,6 +229,10 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) accd[i][e] = 0.0;
+
+    double bbd[VBB ? 10 : 1];  // per-lane partial products of tasks (16+a, 16+b), a <= b
+#pragma unroll
+    for (int i = 0; i < (VBB ? 10 : 1); ++i) bbd[i] = 0.0;
 
     // The loads of the next block (or next two, SVDQ_PREFETCH2) are in flight while a block is computed.
     constexpr int AHEAD = SVDQ_PREFETCH2 ? 2 : 1;
@@ -249,6 +257,19 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
         center_store<NTP, GATHER>(v, NT, center, X, lane);
         wave_sync();
+        if constexpr (VBB) {  // rows 4 lane .. 4 lane + 3 of tasks 16..19, read back from the strip so that the
+            f32x4 xe[4];      // grouping of rows per lane (and with it every bit) is the same in gather mode
+#pragma unroll
+            for (int a = 0; a < 4; ++a) xe[a] = *reinterpret_cast<const f32x4 *>(X + (16 + a) * XS + 4 * lane);
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = a; b < 4; ++b) {
+                    const f32x4 pr = xe[a] * xe[b];
+                    bbd[q++] += (double)((pr.x + pr.y) + (pr.z + pr.w));
+                }
+        }
         if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
             if constexpr (GATHER) {
                 load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
@@ -292,7 +313,7 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
                     for (int e = 0; e < 4; ++e) {
                         acc[0] = mfma4(a0[e], a0[e], acc[0]);
                         acc[1] = mfma4(a0[e], a1[e], acc[1]);
-                        acc[2] = mfma4(a1[e], a1[e], acc[2]);
+                        if constexpr (!VBB) acc[2] = mfma4(a1[e], a1[e], acc[2]);
                     }
                 }
             }
@@ -332,8 +353,25 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
                     dst[m * NT + 16 + c] = accd[1][e];
                     dst[(16 + c) * NT + m] = accd[1][e];
                 }
-                if (16 + m < NT && 16 + c < NT) dst[(16 + m) * NT + 16 + c] = accd[2][e];
+                if constexpr (!VBB) {
+                    if (16 + m < NT && 16 + c < NT) dst[(16 + m) * NT + 16 + c] = accd[2][e];
+                }
             }
+        }
+        if constexpr (VBB) {  // butterfly sum of the per-lane BB partials (fixed order), written once
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = a; b < 4; ++b) {
+                    double t = bbd[q++];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+                    if (lane == 0 && 16 + b < NT) {   // a <= b, so 16 + a < NT as well
+                        dst[(16 + a) * NT + 16 + b] = t;
+                        dst[(16 + b) * NT + 16 + a] = t;
+                    }
+                }
         }
     }
 }

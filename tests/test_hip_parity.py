@@ -333,6 +333,8 @@ def test_single_task_and_all_zero_inputs(sq, orc):
     (300000, 2, 34, 0.90, 4, 2),       # N = 2 (padded to 4 task slots)
     (70001, 13, 35, 0.99, 2, 2),       # N = 13 (padded to 16)
     (40000, 32, 36, 0.90, 4, 2),       # N = 32 (max)
+    (90001, 18, 37, 0.90, 4, 2),       # N = 18: padded to 20, BB block on the vector ALU with two empty slots
+    (50000, 17, 38, 0.95, 4, 2),       # N = 17: a single task beyond the first 16-slot block
 ])
 def test_against_oracle_seeded(sq, orc, D, N, seed, thr, bits, stages):
     deltas = orc.synthetic_deltas(D, N, seed, rank=min(3, N))
