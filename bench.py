@@ -64,6 +64,9 @@ def parse():
                          "then read every task tensor through the combined mask's index list (gather mode)")
     ap.add_argument("--masks-compact", action="store_true",
                     help="A/B: materialise compacted copies of the deltas (the pre-gather schedule) instead")
+    ap.add_argument("--from-base", choices=("off", "fused", "ingest"), default="off",
+                    help="start from fine-tuned + base weights instead of task vectors: 'fused' forms finetuned - base "
+                         "inside the streaming passes (svdq_compress_from_base), 'ingest' runs svdq_ingest first")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -193,6 +196,19 @@ def main():
                         low_bits=args.bits, rtvq_stages=args.stages, device=dev, unit_rows=args.unit_rows,
                         flags=flags)
     table = plan.pointer_table(views)
+    fb = None
+    nat_lib = svdq_amd._native.lib()
+    if args.from_base != "off":
+        # fine-tuned tensors = base + the synthetic deltas; the deltas themselves become the ingest's output buffers
+        from ctypes import c_void_p
+        from svdq_amd.pipeline import _ptr, _stream_ptr
+        gb = torch.Generator(device=dev).manual_seed(99 + rank)
+        base_t = [torch.randn(r, device=dev, generator=gb) for r in rows]
+        ft = [[base_t[p] + views[p][t] for t in range(N)] for p in range(len(rows))]
+        fb = {"base": base_t, "ft": ft,
+              "bt": torch.tensor([b.data_ptr() for b in base_t], dtype=torch.int64).to(dev),
+              "ft_table": plan.pointer_table(ft)}
+        plan._keep = (views, ft)
     mset = rows_dev = None
     if args.masks != "none":
         from svdq_amd.mask_loader import MaskSet
@@ -262,7 +278,13 @@ def main():
             if world > 1:
                 shard.gather_small(plan.small.cpu() if on_cpu else plan.small)
             return
-        if groups:
+        if fb is not None:
+            if args.from_base == "fused":
+                plan.run_from_base(fb["ft_table"], fb["bt"])
+            else:
+                nat_lib.svdq_ingest(plan._h, _ptr(fb["bt"]), _ptr(fb["ft_table"]), _ptr(table), c_void_p(0), _stream_ptr())
+                plan.run(table)
+        elif groups:
             step_pipelined()
         elif events is None or args.pipeline_in_c or args.fused:
             plan.run(table)
@@ -301,7 +323,7 @@ def main():
 
     # per-kernel HIP-event times (this rank), averaged over the timed steps
     kms = [0.0] * 4
-    if not groups and not args.pipeline_in_c and not args.fused and mset is None:
+    if not groups and not args.pipeline_in_c and not args.fused and mset is None and fb is None:
         for s in range(args.steps):
             for i in range(4):
                 kms[i] += ev[s][i].elapsed_time(ev[s][i + 1])
@@ -340,7 +362,7 @@ def main():
                                    f"sum D = {int(sumD)}/GPU, energy {args.energy}, center, fp16 bases, "
                                    f"{args.bits}-bit x {args.stages}-stage RTVQ",
                        "tensors_per_gpu": len(rows), "tasks": N, "mean_rank_k": round(k_mean, 2),
-                       "units": int(plan.sizes.n_units), "pipeline_groups": len(groups), "schedule": "fused" if args.fused else "4 launches",
+                       "units": int(plan.sizes.n_units), "pipeline_groups": len(groups), "schedule": "fused" if args.fused else "4 launches", "from_base": args.from_base,
                        "masks": args.masks, "mask_density": (round(float(sm.rows.sum()) / sumD, 4)
                                                              if args.masks != "none" else None),
                        "sharding": "none" if world == 1 else (

@@ -179,6 +179,15 @@ int svdq_compress_gather(const svdq_plan *plan, const void *delta_ptrs, const vo
                          const int64_t *rows_dev, void *workspace_dev, void *small_dev, void *basis_dev,
                          float *mean_dev, void *stream);
 
+/* svdq_compress straight from checkpoints: finetuned_ptrs [n_params * n_tasks] name the FINE-TUNED tensors,
+ * base_ptrs [n_params] the base model's; delta = finetuned - base (compute_task_vector,
+ * task_vector_loader.py:103-141) is formed in registers inside the streaming passes, so Step 1's task vectors
+ * (cli.py:241-262) are never written to or read back from HBM.  Artifacts are those of svdq_ingest followed by
+ * svdq_compress, bit for bit. */
+int svdq_compress_from_base(const svdq_plan *plan, const void *finetuned_ptrs, const void *base_ptrs,
+                            const int64_t *rows_dev, void *workspace_dev, void *small_dev, void *basis_dev,
+                            float *mean_dev, void *stream);
+
 /* ---- the step before the path: task-vector ingest and whole-tensor quantization ("TVQ"),
  * batched over a plan's parameters x tasks.  All pointer tables are DEVICE arrays of device addresses,
  * parameter-major ([p * n_tasks + t]); fp32 buffers 16-byte aligned, code buffers 4-byte aligned. ---- */

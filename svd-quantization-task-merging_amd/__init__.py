@@ -38,7 +38,7 @@ from .task_vector_loader import (load_checkpoint, compute_task_vector, compute_t
                                  get_task_checkpoint_paths)
 from .task_vectors import TaskVector, QuantizedTaskVector, QuantizedFinetunedModel, QuantizedBaseAndTaskVector
 from .ingest import ElementwiseBatch, ingest_state_dicts, quantize_state_dict, dequantize_payloads
-from .driver import build_bases, run_basis_and_compress
+from .driver import build_bases, run_basis_and_compress, run_basis_and_compress_from_checkpoints
 from .pipeline import CompressPlan, compress_batch
 from . import quantization_utils
 from .quantization_utils import absmax_quantization, dequantize_absmax

@@ -347,7 +347,7 @@ static void unit_range(const svdq_plan *pl, int32_t param0, int32_t nparams, int
 }
 
 static int gram_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, int32_t param0,
-                      int32_t nparams, const void *idx, void *stream) {
+                      int32_t nparams, const void *idx, void *stream, const void *base = nullptr) {
     if (!pl || !ptrs || !workspace) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
@@ -356,7 +356,7 @@ static int gram_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows
     int u0, nu;
     unit_range(pl, param0, nparams, &u0, &nu);
     return svdq_launch_gram(pl, ptrs, rows_dev, reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off)), u0, nu,
-                            pl->cfg.center, idx, (hipStream_t)stream);
+                            pl->cfg.center, idx, base, (hipStream_t)stream);
 }
 
 extern "C" int svdq_gram_center_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
@@ -373,13 +373,13 @@ extern "C" int svdq_task_gram(const svdq_plan *pl, const void *ptrs, const int64
     hipStream_t st = (hipStream_t)stream;
     double *part = reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off));
     double *part2 = reinterpret_cast<double *>(ws(workspace, pl->ws_gram2_off));
-    if (int rc = svdq_launch_gram(pl, ptrs, rows_dev, part, 0, pl->n_units, /*center=*/0, nullptr, st)) return rc;
+    if (int rc = svdq_launch_gram(pl, ptrs, rows_dev, part, 0, pl->n_units, /*center=*/0, nullptr, nullptr, st)) return rc;
     if (int rc = svdq_launch_reduce(pl, part, part2, 0, pl->n_params, st)) return rc;
     return svdq_launch_gram_total(pl, part2, out_gram, st);
 }
 
 static int eig_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, void *small,
-                     int32_t param0, int32_t nparams, const void *idx, void *stream) {
+                     int32_t param0, int32_t nparams, const void *idx, void *stream, const void *base = nullptr) {
     if (!pl || !ptrs || !workspace || !small) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
@@ -392,7 +392,7 @@ static int eig_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
     return svdq_launch_eig(pl, ptrs, rows_dev, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram2_off)),
                            reinterpret_cast<float *>(ws(workspace, pl->ws_w_off)),
                            reinterpret_cast<double *>(ws(workspace, pl->ws_c0_off)), reinterpret_cast<uint8_t *>(small),
-                           param0, nparams, idx, (hipStream_t)stream);
+                           param0, nparams, idx, base, (hipStream_t)stream);
 }
 
 extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
@@ -402,7 +402,8 @@ extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs,
 }
 
 static int bp_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, const void *small,
-                    void *basis, float *mean, int32_t param0, int32_t nparams, const void *idx, void *stream) {
+                    void *basis, float *mean, int32_t param0, int32_t nparams, const void *idx, void *stream,
+                    const void *base = nullptr) {
     if (!pl || !ptrs || !workspace || !small || !basis) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
@@ -420,7 +421,7 @@ static int bp_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_d
                                      reinterpret_cast<const int32_t *>(sm + pl->small.r_off),
                                      reinterpret_cast<uint8_t *>(basis), mean,
                                      reinterpret_cast<double *>(ws(workspace, pl->ws_cpart_off)), u0, nu,
-                                     pl->cfg.reserved & 1, idx, (hipStream_t)stream);
+                                     pl->cfg.reserved & 1, idx, base, (hipStream_t)stream);
 }
 
 extern "C" int svdq_basis_project_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
@@ -557,6 +558,30 @@ extern "C" int svdq_compress_gather(const svdq_plan *pl, const void *ptrs, const
     if (rc == SVDQ_OK) rc = eig_range(pl, ptrs, rows_dev, workspace, small, 0, pl->n_params, index_ptrs, stream);
     if (rc == SVDQ_OK)
         rc = bp_range(pl, ptrs, rows_dev, workspace, small, basis, mean, 0, pl->n_params, index_ptrs, stream);
+    if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
+    return rc;
+}
+
+// Step 0 folded into the path: delta_ptrs of svdq_compress are replaced by the FINE-TUNED tensors and one base
+// tensor per parameter; finetuned - base is formed in registers in both streaming passes (and for row 0 in the
+// eigen-stage), so the task vectors are never materialised: 2 x 4(N+1) + 2N + 4 bytes per row instead of
+// 4(2N+1) for the ingest plus 10N + 4 for the compression.
+extern "C" int svdq_compress_from_base(const svdq_plan *pl, const void *finetuned_ptrs, const void *base_ptrs,
+                                       const int64_t *rows_dev, void *workspace, void *small, void *basis, float *mean,
+                                       void *stream) {
+    if (!pl || !base_ptrs) {
+        svdq_set_error("svdq_compress_from_base: plan and base_ptrs are required");
+        return SVDQ_EINVAL;
+    }
+    if (small)
+        HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(small) + pl->small.status_off, 0, sizeof(int32_t),
+                               (hipStream_t)stream));
+    int rc = gram_range(pl, finetuned_ptrs, rows_dev, workspace, 0, pl->n_params, nullptr, stream, base_ptrs);
+    if (rc == SVDQ_OK)
+        rc = eig_range(pl, finetuned_ptrs, rows_dev, workspace, small, 0, pl->n_params, nullptr, stream, base_ptrs);
+    if (rc == SVDQ_OK)
+        rc = bp_range(pl, finetuned_ptrs, rows_dev, workspace, small, basis, mean, 0, pl->n_params, nullptr, stream,
+                      base_ptrs);
     if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
     return rc;
 }

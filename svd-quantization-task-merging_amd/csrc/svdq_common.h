@@ -72,18 +72,21 @@ static inline int svdq_ntp(int n) { return (n + 3) / 4 * 4; }
 void svdq_set_error(const char *fmt, ...);
 
 // launchers (defined in the .hip files)
-// idx: NULL, or a device table [n_params] of int32 index lists (gather mode, see svdq_compress_gather)
+// idx: NULL, or a device table [n_params] of int32 index lists (gather mode, see svdq_compress_gather);
+// base: NULL, or a device table [n_params] of base tensors (minus-base mode, see svdq_compress_from_base)
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                     int unit0, int nunits, int center, const void *idx, hipStream_t st);
+                     int unit0, int nunits, int center, const void *idx, const void *base, hipStream_t st);
 int svdq_launch_gram_total(const svdq_plan *pl, const double *part2, double *out, hipStream_t st);
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
-                              double *cpart, int unit0, int nunits, int reverse, const void *idx, hipStream_t st);
+                              double *cpart, int unit0, int nunits, int reverse, const void *idx, const void *base,
+                              hipStream_t st);
 int svdq_launch_fused(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
                       double *gram_part2, float *W, double *c0, uint8_t *small, uint8_t *basis, float *mean,
                       double *cpart, hipStream_t st);
 int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W,
-                    double *c0, uint8_t *small, int param0, int nparams, const void *idx, hipStream_t st);
+                    double *c0, uint8_t *small, int param0, int nparams, const void *idx, const void *base,
+                    hipStream_t st);
 int svdq_launch_reduce(const svdq_plan *pl, const double *part, double *part2, int param0, int nparams,
                        hipStream_t st);
 int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, const double *c0, uint8_t *small, int param0,

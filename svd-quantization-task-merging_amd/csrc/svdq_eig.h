@@ -79,7 +79,8 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
                           const double *__restrict__ gram_part2, float *__restrict__ Wtab,
                           double *__restrict__ c0_out, float *__restrict__ sigma_out, int32_t *__restrict__ k_out,
                           int32_t *__restrict__ r_out, float *__restrict__ energy_out,
-                          int64_t *__restrict__ rows_out, const int32_t *const *__restrict__ idx_ptrs = nullptr) {
+                          int64_t *__restrict__ rows_out, const int32_t *const *__restrict__ idx_ptrs = nullptr,
+                          const float *const *__restrict__ base_ptrs = nullptr) {
 #pragma clang fp contract(off)
     constexpr int LDX = NMAX + 1;      // padded leading dimension
     double *Gd = lds;                  // [NMAX*NMAX] (deflated) Gram, kept for the completion column
@@ -291,7 +292,12 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
         A[t * LDX + i] = wv;
     }
     // row 0 of every task (gather mode: the first selected element of the tensor)
-    if (tid < n && D > 0) lam[tid] = (double)ptrs[(size_t)p * n + tid][idx_ptrs ? idx_ptrs[p][0] : 0];
+    if (tid < n && D > 0) {
+        const int64_t i0 = idx_ptrs ? idx_ptrs[p][0] : 0;
+        float x0 = ptrs[(size_t)p * n + tid][i0];
+        if (base_ptrs) x0 = x0 - base_ptrs[p][i0];   // minus-base mode: the delta is formed exactly as in the passes
+        lam[tid] = (double)x0;
+    }
     phase_sync<THREADS>();
 
     // Orthonormal completion of the first null direction (the one centring always creates; LAPACK

@@ -97,12 +97,13 @@ __global__ __launch_bounds__(THREADS) void k_eig(const SvdqParam *__restrict__ p
                                                  float *__restrict__ sigma_out, int32_t *__restrict__ k_out,
                                                  int32_t *__restrict__ r_out, float *__restrict__ energy_out,
                                                  int64_t *__restrict__ rows_out,
-                                                 const int32_t *const *__restrict__ idx_ptrs) {
+                                                 const int32_t *const *__restrict__ idx_ptrs,
+                                                 const float *const *__restrict__ base_ptrs) {
     __shared__ __attribute__((aligned(16))) double lds[SVDQ_EIG_LDS_BYTES(NMAX) / 8 + 1];
     const int p = param0 + blockIdx.x;
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
     eig_param<THREADS, NMAX>(lds, p, threadIdx.x, D, ptrs, NT, center, thr, max_rank, gram_part2, Wtab, c0_out, sigma_out,
-                             k_out, r_out, energy_out, rows_out, idx_ptrs);
+                             k_out, r_out, energy_out, rows_out, idx_ptrs, base_ptrs);
 }
 
 // ------------------------------------------------------------------------------------ epilogue
@@ -190,8 +191,10 @@ __global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restri
 
 // ------------------------------------------------------------------------------------ launchers
 int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part2, float *W,
-                    double *c0, uint8_t *small, int param0, int nparams, const void *idx, hipStream_t st) {
+                    double *c0, uint8_t *small, int param0, int nparams, const void *idx, const void *base,
+                    hipStream_t st) {
     auto ip = reinterpret_cast<const int32_t *const *>(idx);
+    auto bpp = reinterpret_cast<const float *const *>(base);
     const svdq_small_layout &L = pl->small;
     auto pp = reinterpret_cast<const float *const *>(ptrs);
     float *sg = reinterpret_cast<float *>(small + L.sigma_off);
@@ -201,11 +204,11 @@ int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_d
     if (pl->n_tasks <= 8)
         hipLaunchKernelGGL((k_eig<64, 8>), dim3(nparams), dim3(64), 0, st, pl->d_params, pp, rows_dev, pl->n_tasks,
                            pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part2, W, c0, param0, sg,
-                           kk, rr, en, ro, ip);
+                           kk, rr, en, ro, ip, bpp);
     else
         hipLaunchKernelGGL((k_eig<256, 32>), dim3(nparams), dim3(256), 0, st, pl->d_params, pp, rows_dev, pl->n_tasks,
                            pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part2, W, c0, param0, sg,
-                           kk, rr, en, ro, ip);
+                           kk, rr, en, ro, ip, bpp);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 

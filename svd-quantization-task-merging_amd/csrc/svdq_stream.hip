@@ -135,6 +135,19 @@ __device__ __forceinline__ i32x4 load_idx(gint *idx, int64_t rb, int64_t D, int 
     return o;
 }
 
+// "Minus base" mode (svdq_compress_from_base): the task tensors are FINE-TUNED weights and the delta
+// finetuned - base is formed in registers, so the task vectors are never written to or read back from HBM.
+__device__ __forceinline__ f32x4 load_base(gfloat *b, int64_t rb, int64_t D, int lane) {
+    const int64_t r = rb + 4 * lane;
+    if (rb + SVDQ_BLK_ROWS <= D) return *reinterpret_cast<gf32x4 *>(b + r);
+    f32x4 o = zero4();
+    if (r < D) o.x = b[r];
+    if (r + 1 < D) o.y = b[r + 1];
+    if (r + 2 < D) o.z = b[r + 2];
+    if (r + 3 < D) o.w = b[r + 3];
+    return o;
+}
+
 template <int NTP>
 __device__ __forceinline__ void load_block_gather(f32x4 (&v)[NTP], gfloat *(&bp)[NTP], const i32x4 &ix, bool full) {
     if (full) {
@@ -195,14 +208,17 @@ __device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int
 // ------------------------------------------------------------------------------------ pass 1
 // One work unit of pass 1 (a run of 256-row blocks of one parameter) by ONE wavefront.
 // X: NTP*XS floats of wave-private LDS.
-template <int NTP, bool GATHER = false>
+// MODE 0: contiguous task vectors; 1: gather through an index list (aux[p] = int32 list); 2: fine-tuned tensors
+// minus a base tensor (aux[p] = base)
+template <int NTP, int MODE = 0>
 __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *__restrict__ params,
                                           const SvdqUnit *__restrict__ units,
                                           const float *const *__restrict__ ptrs,
                                           const int64_t *__restrict__ rows_dev, int NT, int center,
                                           double *__restrict__ gram_part,
-                                          const int32_t *const *__restrict__ idx_ptrs = nullptr) {
-    static_assert(!(GATHER && SVDQ_PREFETCH2), "gather mode supports the one-block-ahead pipeline only");
+                                          const void *const *__restrict__ aux = nullptr) {
+    constexpr bool GATHER = (MODE == 1), SUB = (MODE == 2);
+    static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
     // N = 17..20: the BB block of the 2x2-blocked Gram is only 4 x 4.  A 16x16x4 MFMA per k-step for it wastes 15/16
@@ -239,8 +255,10 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     f32x4 v0[NTP];
     gint *gidx = nullptr;
     i32x4 ixn = {-1, -1, -1, -1};  // indices of the block after the one whose data is in flight
+    gfloat *gbase = nullptr;
+    f32x4 vb = zero4();  // base rows of the block whose fine-tuned rows sit in v
     if constexpr (GATHER) {
-        gidx = (gint *)idx_ptrs[p];
+        gidx = (gint *)aux[p];
         if (r_begin < r_end) {
             const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
             load_block_gather<NTP>(v0, bp, ix0, r_begin + SVDQ_BLK_ROWS <= D);
@@ -248,6 +266,10 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
         }
     } else {
         if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
+        if constexpr (SUB) {
+            gbase = (gfloat *)aux[p];
+            if (r_begin < r_end) vb = load_base(gbase, r_begin, D, lane);
+        }
     }
 #if SVDQ_PREFETCH2
     f32x4 v1[NTP];
@@ -255,6 +277,10 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
 #endif
 
     auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
+        if constexpr (SUB) {
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) v[t] = v[t] - vb;
+        }
         center_store<NTP, GATHER>(v, NT, center, X, lane);
         wave_sync();
         if constexpr (VBB) {  // rows 4 lane .. 4 lane + 3 of tasks 16..19, read back from the strip so that the
@@ -276,6 +302,7 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
                 if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
             } else {
                 load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
+                if constexpr (SUB) vb = load_base(gbase, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
             }
         }
 
@@ -376,15 +403,15 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
     }
 }
 
-template <int NTP, bool GATHER>
+template <int NTP, int MODE>
 __global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ params,
                                              const SvdqUnit *__restrict__ units,
                                              const float *const *__restrict__ ptrs,
                                              const int64_t *__restrict__ rows_dev, int NT, int center,
                                              double *__restrict__ gram_part, int unit0,
-                                             const int32_t *const *__restrict__ idx_ptrs) {
+                                             const void *const *__restrict__ aux) {
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
-    gram_unit<NTP, GATHER>(X, unit0 + (int)blockIdx.x, params, units, ptrs, rows_dev, NT, center, gram_part, idx_ptrs);
+    gram_unit<NTP, MODE>(X, unit0 + (int)blockIdx.x, params, units, ptrs, rows_dev, NT, center, gram_part, aux);
 }
 
 // ------------------------------------------------------------------------------------ pass 2
@@ -432,14 +459,15 @@ __device__ __forceinline__ bf16x8 pack_bf16(const f32x4 &lo, const f32x4 &hi) {
 // 2^-12 term is 2^-21 of c, below the fp32 accumulation noise of the direct product.
 // One work unit of pass 2 by ONE wavefront.  X: NTP*XS floats, OUT: SVDQ_BLK_ROWS*NTP + 16 elements of
 // wave-private LDS.
-template <int NTP, bool OUT16, bool GATHER = false>
+template <int NTP, bool OUT16, int MODE = 0>
 __device__ __forceinline__ void bp_unit(
     float *X, typename OutT<OUT16>::type *OUT, int uidx, const SvdqParam *__restrict__ params,
     const SvdqUnit *__restrict__ units, const float *const *__restrict__ ptrs,
     const int64_t *__restrict__ rows_dev, int NT, int center, const float *__restrict__ Wtab,
     const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev, uint8_t *__restrict__ basis,
-    float *__restrict__ meanbuf, double *__restrict__ cpart, const int32_t *const *__restrict__ idx_ptrs = nullptr) {
-    static_assert(!(GATHER && SVDQ_PREFETCH2), "gather mode supports the one-block-ahead pipeline only");
+    float *__restrict__ meanbuf, double *__restrict__ cpart, const void *const *__restrict__ aux = nullptr) {
+    constexpr bool GATHER = (MODE == 1), SUB = (MODE == 2);
+    static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
     constexpr int KS = NTP / 4;
@@ -522,8 +550,10 @@ __device__ __forceinline__ void bp_unit(
     f32x4 v0[NTP];
     gint *gidx = nullptr;
     i32x4 ixn = {-1, -1, -1, -1};  // indices of the block after the one whose data is in flight
+    gfloat *gbase = nullptr;
+    f32x4 vb = zero4();  // base rows of the block whose fine-tuned rows sit in v
     if constexpr (GATHER) {
-        gidx = (gint *)idx_ptrs[p];
+        gidx = (gint *)aux[p];
         if (r_begin < r_end) {
             const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
             load_block_gather<NTP>(v0, bp, ix0, r_begin + SVDQ_BLK_ROWS <= D);
@@ -531,6 +561,10 @@ __device__ __forceinline__ void bp_unit(
         }
     } else {
         if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
+        if constexpr (SUB) {
+            gbase = (gfloat *)aux[p];
+            if (r_begin < r_end) vb = load_base(gbase, r_begin, D, lane);
+        }
     }
 #if SVDQ_PREFETCH2
     f32x4 v1[NTP];
@@ -538,6 +572,10 @@ __device__ __forceinline__ void bp_unit(
 #endif
 
     auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
+        if constexpr (SUB) {
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) v[t] = v[t] - vb;
+        }
         const f32x4 mean = center_store<NTP, GATHER>(v, NT, center, X, lane);
 #ifdef SVDQ_ABLATE_STORES
         if (gmean && D < 0) {
@@ -566,6 +604,7 @@ __device__ __forceinline__ void bp_unit(
                 if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
             } else {
                 load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
+                if constexpr (SUB) vb = load_base(gbase, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
             }
         }
 
@@ -697,19 +736,19 @@ UNROLL_N(SVDQ_UNROLL_BP)
     }
 }
 
-template <int NTP, bool OUT16, bool GATHER>
+template <int NTP, bool OUT16, int MODE>
 __global__ __launch_bounds__(64) void k_basis_project(
     const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
     const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
     const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
     uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse,
-    const int32_t *const *__restrict__ idx_ptrs) {
+    const void *const *__restrict__ aux) {
     using out_t = typename OutT<OUT16>::type;
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
     __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];  // +16: dump slot for idle lanes
     const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
-    bp_unit<NTP, OUT16, GATHER>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis,
-                                meanbuf, cpart, idx_ptrs);
+    bp_unit<NTP, OUT16, MODE>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis,
+                              meanbuf, cpart, aux);
 }
 
 // ------------------------------------------------------------------------------------ N > 16: two waves
@@ -760,16 +799,27 @@ __device__ __forceinline__ f32x4 center_store_half(const f32x4 (&v)[HT], int t0,
 }
 
 // first block + one-block-ahead loads of one wave's HT tasks (contiguous or through the index list)
-template <int HT, bool GATHER>
+template <int HT, int MODE>
 struct HalfLoader {
+    static constexpr bool GATHER = (MODE == 1), SUB = (MODE == 2);
     gfloat *bp[HT];
     gint *gidx;
+    gfloat *gbase;
     i32x4 ixn;
+    f32x4 vb;
     int64_t D, r_end;
     int lane;
+    __device__ __forceinline__ void apply(f32x4 (&v)[HT]) {  // minus-base mode: v holds fine-tuned rows
+        if constexpr (SUB) {
+#pragma unroll
+            for (int i = 0; i < HT; ++i) v[i] = v[i] - vb;
+        }
+    }
     __device__ __forceinline__ void first(f32x4 (&v)[HT], int64_t r_begin) {
         ixn = i32x4{-1, -1, -1, -1};
+        vb = zero4();
         if (r_begin >= r_end) return;
+        if constexpr (SUB) vb = load_base(gbase, r_begin, D, lane);
         if constexpr (GATHER) {
             const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
             load_block_gather<HT>(v, bp, ix0, r_begin + SVDQ_BLK_ROWS <= D);
@@ -785,6 +835,7 @@ struct HalfLoader {
             if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
         } else {
             load_block<HT>(v, bp, rb + SVDQ_BLK_ROWS, D, lane);
+            if constexpr (SUB) vb = load_base(gbase, rb + SVDQ_BLK_ROWS, D, lane);
         }
     }
 };
@@ -799,14 +850,15 @@ __device__ __forceinline__ void copy_out_wg(const void *lds_src, uint8_t *gdst, 
         *reinterpret_cast<uint16_t *>(gdst + b) = *reinterpret_cast<const uint16_t *>(sb + b);
 }
 
-template <int NTP, bool OUT16, bool GATHER>
+template <int NTP, bool OUT16, int MODE>
 __global__ __launch_bounds__(128) void k_basis_project2(
     const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
     const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
     const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
     uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse,
-    const int32_t *const *__restrict__ idx_ptrs) {
+    const void *const *__restrict__ aux) {
     static_assert(NTP > 16 && NTP <= 32 && NTP % 4 == 0, "two-wave variant is for 16 < N <= 32");
+    constexpr bool GATHER = (MODE == 1);
     using out_t = typename OutT<OUT16>::type;
     constexpr int HT = NTP / 2;
     constexpr int KS = NTP / 4;
@@ -826,10 +878,11 @@ __global__ __launch_bounds__(128) void k_basis_project2(
     const int k = k_dev[p], r = r_dev[p], nl = r - k;
     const int t0 = wv * HT;
 
-    HalfLoader<HT, GATHER> ld;
+    HalfLoader<HT, MODE> ld;
 #pragma unroll
     for (int i = 0; i < HT; ++i) ld.bp[i] = (gfloat *)ptrs[(size_t)p * NT + (t0 + i < NT ? t0 + i : NT - 1)];
-    ld.gidx = GATHER ? (gint *)idx_ptrs[p] : nullptr;
+    ld.gidx = GATHER ? (gint *)aux[p] : nullptr;
+    ld.gbase = (MODE == 2) ? (gfloat *)aux[p] : nullptr;
     ld.D = D;
     ld.r_end = r_end;
     ld.lane = lane;
@@ -877,6 +930,7 @@ __global__ __launch_bounds__(128) void k_basis_project2(
     f32x4 v[HT];
     ld.first(v, r_begin);
     for (int64_t rb = r_begin; rb < r_end; rb += SVDQ_BLK_ROWS) {
+        ld.apply(v);
         const f32x4 mean = center_store_half<HT, GATHER>(v, t0, NT, center, X, SUM, wv, lane);
         if (gmean && wv == 0) {
             if constexpr (GATHER) {
@@ -1139,30 +1193,33 @@ int svdq_launch_fused(const svdq_plan *pl, const void *ptrs, const int64_t *rows
 // ------------------------------------------------------------------------------------ launchers
 template <int NTP>
 static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                         int unit0, int nunits, int center, const void *idx, hipStream_t st) {
-    auto ip = reinterpret_cast<const int32_t *const *>(idx);
-    if (idx)
-        hipLaunchKernelGGL((k_gram<NTP, true>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units,
-                           reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks, center, gram_part, unit0,
-                           ip);
-    else
-        hipLaunchKernelGGL((k_gram<NTP, false>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units,
-                           reinterpret_cast<const float *const *>(ptrs), rows_dev, pl->n_tasks, center, gram_part, unit0,
-                           ip);
+                         int unit0, int nunits, int center, const void *idx, const void *base, hipStream_t st) {
+    auto pp = reinterpret_cast<const float *const *>(ptrs);
+#define SVDQ_LAUNCH_GRAM(M, AUX)                                                                                   \
+    hipLaunchKernelGGL((k_gram<NTP, M>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, rows_dev, \
+                       pl->n_tasks, center, gram_part, unit0, (const void *const *)(const void *)(AUX))
+    if (idx) SVDQ_LAUNCH_GRAM(1, idx);
+    else if (base) SVDQ_LAUNCH_GRAM(2, base);
+    else SVDQ_LAUNCH_GRAM(0, nullptr);
+#undef SVDQ_LAUNCH_GRAM
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                     int unit0, int nunits, int center, const void *idx, hipStream_t st) {
+                     int unit0, int nunits, int center, const void *idx, const void *base, hipStream_t st) {
+    if (idx && base) {
+        svdq_set_error("gather mode and minus-base mode cannot be combined");
+        return SVDQ_EUNSUPPORTED;
+    }
     switch (pl->ntp) {
-        case 4: return launch_gram_t<4>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
-        case 8: return launch_gram_t<8>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
-        case 12: return launch_gram_t<12>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
-        case 16: return launch_gram_t<16>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
-        case 20: return launch_gram_t<20>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
-        case 24: return launch_gram_t<24>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
-        case 28: return launch_gram_t<28>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
-        case 32: return launch_gram_t<32>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, st);
+        case 4: return launch_gram_t<4>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
+        case 8: return launch_gram_t<8>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
+        case 12: return launch_gram_t<12>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
+        case 16: return launch_gram_t<16>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
+        case 20: return launch_gram_t<20>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
+        case 24: return launch_gram_t<24>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
+        case 28: return launch_gram_t<28>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
+        case 32: return launch_gram_t<32>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
     }
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;
@@ -1171,24 +1228,24 @@ int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
 template <int NTP>
 static int launch_bp_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                        const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
-                       int unit0, int nunits, int reverse, const void *idx, hipStream_t st) {
+                       int unit0, int nunits, int reverse, const void *idx, const void *base, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
-    auto ip = reinterpret_cast<const int32_t *const *>(idx);
-#define SVDQ_LAUNCH_BP(F16, G)                                                                                        \
+#define SVDQ_LAUNCH_BP(F16, M, AUX)                                                                                   \
     do {                                                                                                              \
+        auto ax = (const void *const *)(const void *)(AUX);                                                         \
         if constexpr (NTP > 16)                                                                                       \
-            hipLaunchKernelGGL((k_basis_project2<NTP, F16, G>), dim3(nunits), dim3(128), 0, st, pl->d_params,         \
+            hipLaunchKernelGGL((k_basis_project2<NTP, F16, M>), dim3(nunits), dim3(128), 0, st, pl->d_params,         \
                                pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
-                               cpart, unit0, reverse, ip);                                                            \
+                               cpart, unit0, reverse, ax);                                                            \
         else                                                                                                          \
-            hipLaunchKernelGGL((k_basis_project<NTP, F16, G>), dim3(nunits), dim3(64), 0, st, pl->d_params,           \
+            hipLaunchKernelGGL((k_basis_project<NTP, F16, M>), dim3(nunits), dim3(64), 0, st, pl->d_params,           \
                                pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
-                               cpart, unit0, reverse, ip);                                                            \
+                               cpart, unit0, reverse, ax);                                                            \
     } while (0)
     if (pl->cfg.fp16) {
-        if (idx) SVDQ_LAUNCH_BP(true, true); else SVDQ_LAUNCH_BP(true, false);
+        if (idx) SVDQ_LAUNCH_BP(true, 1, idx); else if (base) SVDQ_LAUNCH_BP(true, 2, base); else SVDQ_LAUNCH_BP(true, 0, nullptr);
     } else {
-        if (idx) SVDQ_LAUNCH_BP(false, true); else SVDQ_LAUNCH_BP(false, false);
+        if (idx) SVDQ_LAUNCH_BP(false, 1, idx); else if (base) SVDQ_LAUNCH_BP(false, 2, base); else SVDQ_LAUNCH_BP(false, 0, nullptr);
     }
 #undef SVDQ_LAUNCH_BP
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
@@ -1196,16 +1253,21 @@ static int launch_bp_t(const svdq_plan *pl, const void *ptrs, const int64_t *row
 
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
-                              double *cpart, int unit0, int nunits, int reverse, const void *idx, hipStream_t st) {
+                              double *cpart, int unit0, int nunits, int reverse, const void *idx, const void *base,
+                              hipStream_t st) {
+    if (idx && base) {
+        svdq_set_error("gather mode and minus-base mode cannot be combined");
+        return SVDQ_EUNSUPPORTED;
+    }
     switch (pl->ntp) {
-        case 4: return launch_bp_t<4>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
-        case 8: return launch_bp_t<8>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
-        case 12: return launch_bp_t<12>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
-        case 16: return launch_bp_t<16>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
-        case 20: return launch_bp_t<20>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
-        case 24: return launch_bp_t<24>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
-        case 28: return launch_bp_t<28>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
-        case 32: return launch_bp_t<32>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, st);
+        case 4: return launch_bp_t<4>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+        case 8: return launch_bp_t<8>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+        case 12: return launch_bp_t<12>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+        case 16: return launch_bp_t<16>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+        case 20: return launch_bp_t<20>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+        case 24: return launch_bp_t<24>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+        case 28: return launch_bp_t<28>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+        case 32: return launch_bp_t<32>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
     }
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;

@@ -17,13 +17,18 @@ _BATCH_KEY = "_svdq_batch"
 
 
 def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks: Optional[Dict[str, torch.Tensor]],
-                config, device="cuda") -> Dict[str, Dict]:
+                config, device="cuda", base_state: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, Dict]:
     """Step 4 for all parameters.  Returns ``bases`` (reference layout: {param: {"masked": basis|None,
     "noise": basis|None}}), already cast to fp16 when ``config.svd_fp16`` (cli.py:354-361), with the
     coefficients of Step 5 attached for ``compress_all_parameters``."""
     dev = resolve_device(device)
     combined_masks = combined_masks or {}
+    if base_state is not None and combined_masks:
+        raise ValueError("compressing straight from checkpoints (base_state) does not combine with masks; "
+                         "materialise the task vectors (load_task_vectors) for a masked run")
     names = sorted({n for tv in task_vectors.values() for n in tv.keys()})
+    if base_state is not None:   # compute_task_vector's eligibility (task_vector_loader.py:126-139)
+        names = [n for n in names if n in base_state and base_state[n].is_floating_point()]
     tasks = list(task_vectors.keys())
     include_noise = bool(config.svd_include_noise)
     min_size = int(config.svd_min_mask_size)
@@ -37,7 +42,8 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
     with torch.cuda.device(dev):
         masked_by_n: Dict[int, List[tuple]] = {}
         for name in names:
-            present = [t for t in tasks if name in task_vectors[t]]
+            present = [t for t in tasks if name in task_vectors[t]
+                       and (base_state is None or task_vectors[t][name].shape == base_state[name].shape)]
             if not present:
                 continue
             deltas = [task_vectors[t][name] for t in present]
@@ -50,7 +56,8 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
                     continue
                 groups.setdefault((len(present), False), []).append(
                     {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": None,
-                     "upper": vs[0].numel(), "min": 0})
+                     "upper": vs[0].numel(), "min": 0,
+                     "base": prepare_vector(base_state[name], dev) if base_state is not None else None})
         # every masked parameter of a group gets ONE batched index build (signal and, when asked, noise in the same
         # pass): the compressor then reads the original task tensors through the index lists (gather mode), so no
         # compacted copies of the deltas are ever written; mask.sum() stays on the device and becomes rows_dev
@@ -100,6 +107,10 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
             if gather:
                 itab = torch.tensor([e["index"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
                 plan.run_gather(table, itab, rows_dev)
+            elif base_state is not None:
+                btab = torch.tensor([e["base"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
+                keep.append([e["base"] for e in entries])
+                plan.run_from_base(table, btab, rows_dev)
             else:
                 plan.run(table, rows_dev)
             small = plan.fetch_small()
@@ -151,3 +162,14 @@ def run_basis_and_compress(task_vectors, combined_masks, config, device="cuda") 
     from .compress import compress_all_parameters
     bases = build_bases(task_vectors, combined_masks, config, device)
     return bases, compress_all_parameters(task_vectors, combined_masks or {}, bases, config, device)
+
+
+def run_basis_and_compress_from_checkpoints(base_state: Dict[str, torch.Tensor],
+                                            finetuned_states: Dict[str, Dict[str, torch.Tensor]], config,
+                                            device="cuda") -> Tuple[Dict, Dict]:
+    """cli.py Step 1 + Step 4 + Step 5 without materialising the task vectors: ``finetuned - base`` is formed
+    inside the two streaming passes (svdq_compress_from_base).  Same (bases, compressed_all) as
+    load_task_vectors + run_basis_and_compress, bit for bit; unmasked runs only."""
+    from .compress import compress_all_parameters
+    bases = build_bases(finetuned_states, None, config, device, base_state=base_state)
+    return bases, compress_all_parameters(finetuned_states, {}, bases, config, device)

@@ -210,6 +210,13 @@ class CompressPlan:
                                                 _ptr(self.workspace), _ptr(self.small), _ptr(self.basis),
                                                 _ptr(self.mean), _stream_ptr()), "svdq_compress_gather")
 
+    def run_from_base(self, finetuned_table, base_table, rows_dev=None):
+        """run() straight from checkpoints: ``finetuned_table`` [P*N] names the fine-tuned tensors, ``base_table``
+        [P] the base model's; finetuned - base is formed inside the streaming passes (no task vectors in HBM)."""
+        nat.check(self.lib.svdq_compress_from_base(self._h, _ptr(finetuned_table), _ptr(base_table), _ptr(rows_dev),
+                                                   _ptr(self.workspace), _ptr(self.small), _ptr(self.basis),
+                                                   _ptr(self.mean), _stream_ptr()), "svdq_compress_from_base")
+
     # ---- outputs
     def fetch_small(self) -> SmallArtifacts:
         host = self.small.cpu().numpy()  # the one D2H copy (synchronises the stream)

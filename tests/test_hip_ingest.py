@@ -175,3 +175,59 @@ def test_ingest_full_size_and_fused_statistics(sq):
         assert torch.equal(fused[t], base + plain[t])
         assert float((plain[t] - deltas[t]).abs().max()) <= 0.5 / s1[t].item() * (1 + 1e-5)
     batch.close()
+
+
+@pytest.mark.parametrize("N,fp16", [(8, True), (3, False), (20, True), (16, True)])
+def test_compress_from_base_equals_ingest_then_compress(sq, N, fp16):
+    """svdq_compress_from_base (finetuned - base formed inside the streaming passes) produces exactly the artifacts
+    of svdq_ingest followed by svdq_compress."""
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    sizes = [300000, 777, 70001, 1024 * 96 + 2, 12]
+    g = torch.Generator().manual_seed(41)
+    base = [torch.randn(D, generator=g).to(dev) for D in sizes]
+    deltas = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 590 + i)] for i, D in enumerate(sizes)]
+    fts = [[base[p] + deltas[p][t] for t in range(N)] for p in range(len(sizes))]
+    batch = sq.ElementwiseBatch(sizes, N, dev)
+    ing = batch.ingest(base, [f for fs in fts for f in fs])
+    vecs = [ing[p * N:(p + 1) * N] for p in range(len(sizes))]
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=fp16, low_bits=4, rtvq_stages=2, device=dev,
+              unit_rows=1024)
+    ref = CompressPlan(sizes, N, **kw)
+    ref.run(ref.pointer_table(vecs))
+    fb = CompressPlan(sizes, N, **kw)
+    btab = torch.tensor([b.data_ptr() for b in base], dtype=torch.int64).to(dev)
+    fb.run_from_base(fb.pointer_table(fts), btab)
+    torch.cuda.synchronize()
+    sm, sf = ref.fetch_small(), fb.fetch_small()
+    assert torch.equal(fb.small, ref.small)
+    for p, D in enumerate(sizes):
+        a = ref.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), D)
+        b = fb.basis_tensors(p, int(sf.k[p]), int(sf.r[p]), D)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    batch.close()
+
+
+def test_run_from_checkpoints_matches_task_vector_route(sq, g):
+    base, fts = _states(g)
+    base = {k: v for k, v in base.items() if v.is_floating_point()}
+    fts = {t: {k: v for k, v in sd.items() if k in base and v.shape == base[k].shape} for t, sd in fts.items()}
+    fts["C"]["w2"] = fts["A"]["w2"] * 1.01          # every task has every parameter: N >= 3 everywhere
+    fts["B"]["b1"] = fts["A"]["b1"] + 0.001
+    cfg = sq.SVDHybridConfig(svd_energy_threshold=0.9, svd_max_rank=2)
+    tv = sq.compute_task_vectors(base, fts, device="cuda")
+    bases1, comp1 = sq.run_basis_and_compress(tv, {}, cfg, "cuda")
+    bases2, comp2 = sq.run_basis_and_compress_from_checkpoints(base, fts, cfg, "cuda")
+    assert sorted(bases1) == sorted(bases2) and sorted(comp1) == sorted(comp2)
+    for name in bases1:
+        b1, b2 = bases1[name]["masked"], bases2[name]["masked"]
+        assert b1["k"] == b2["k"] and torch.equal(b1["U_high"], b2["U_high"]) and torch.equal(b1["U_low"], b2["U_low"])
+        assert torch.equal(b1["mean"], b2["mean"])
+        for t in comp1[name]:
+            a1, a2 = comp1[name][t]["masked"], comp2[name][t]["masked"]
+            assert torch.equal(a1["c_high_fp16"], a2["c_high_fp16"])
+            for p1, p2 in zip(a1["c_low_quant"]["payloads"], a2["c_low_quant"]["payloads"]):
+                assert torch.equal(p1["quantized"], p2["quantized"])
+                assert bits_equal(p1["scale"].numpy(), p2["scale"].numpy())      # NaN == NaN (F4: one-element c_low)
+    with pytest.raises(ValueError, match="does not combine with masks"):
+        sq.build_bases(fts, {"w1": torch.ones(40, 30, dtype=torch.bool)}, cfg, "cuda", base_state=base)
