@@ -29,10 +29,11 @@ from .clustering import (cluster_tasks, task_gram, cluster_from_gram, cluster_st
                          compute_kmeans_clustering, compute_hierarchical_clustering)
 from .diagnostics import (compute_reconstruction_error, compute_parameter_diagnostics, compute_all_diagnostics,
                           compute_compression_statistics, print_detailed_compression_report,
-                          print_diagnostics_summary)
+                          print_diagnostics_summary, compute_coefficient_histograms)
 from .storage import (save_basis, load_basis, save_compressed_coefficients, load_compressed_coefficients,
                       save_diagnostics, load_diagnostics, save_config, load_config, save_all_artifacts,
-                      load_all_artifacts, save_merged_model, reconstruct_from_artifacts)
+                      load_all_artifacts, save_merged_model, reconstruct_from_artifacts,
+                      reload_merged_model_from_artifacts)
 from .task_vector_loader import (load_checkpoint, compute_task_vector, compute_task_vectors, load_task_vectors,
                                  get_parameter_names, organize_by_parameter, flatten_task_deltas,
                                  get_task_checkpoint_paths)

@@ -110,6 +110,11 @@ def run_svd_hybrid_pipeline(config: SVDHybridConfig) -> Dict:
             "compressed": compressed_all, "compression_statistics": stats}
 
 
+def run_svd_hybrid(config: SVDHybridConfig) -> Dict:
+    """Reference run.py:40-65."""
+    return run_svd_hybrid_pipeline(config)
+
+
 def parse_args(argv=None):
     """cli.py:781-875: the reference's flags and defaults."""
     p = argparse.ArgumentParser(description="SVD-Hybrid merging method combining Tall Masks and TVQ (MI355X HIP path)")

@@ -211,3 +211,25 @@ def print_diagnostics_summary(diagnostics: Dict) -> None:
     s = diagnostics.get("summary", {})
     print(f"   reconstruction: average relative error {s.get('average_reconstruction_error', 0):.6f} over "
           f"{s.get('num_parameters', len(diagnostics.get('per_parameter', {})))} parameters")
+
+
+def compute_coefficient_histograms(compressed_params: Dict[str, Dict], quantizer, num_bins: int = 50,
+                                   device: str = "cpu") -> Dict:
+    """Reference diagnostics.py:324-382: histograms of |c_high| and |dequantized c_low| over the tasks of one
+    parameter (a few hundred scalars: numpy on the host after the GPU dequantization)."""
+    import numpy as np
+    highs, lows = [], []
+    for art in compressed_params.values():
+        if art is None or art.get("masked") is None:
+            continue
+        highs.append(art["masked"]["c_high_fp16"].float().flatten().cpu())
+        lows.append(quantizer.dequantize(art["masked"]["c_low_quant"], device=device).float().flatten().cpu())
+    if not highs:
+        return {}
+    out = {}
+    for key, parts in (("c_high", highs), ("c_low", lows)):
+        a = np.abs(torch.cat(parts).numpy())
+        counts, edges = np.histogram(a, bins=num_bins)
+        out[key] = {"counts": counts.tolist(), "bin_edges": edges.tolist(), "mean": float(np.mean(a)),
+                    "std": float(np.std(a)), "max": float(np.max(a))}
+    return out

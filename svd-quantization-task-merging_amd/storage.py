@@ -201,3 +201,19 @@ def reconstruct_from_artifacts(artifact_dir: str, base_model_path, output_path: 
     if output_path:
         torch.save(out, output_path)
     return {"merged_state_dict": out, "diagnostics": diagnostics, "config": config}
+
+
+def reload_merged_model_from_artifacts(artifact_dir: str, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """Reference reload.py:60-139: a pre-saved merged_state_dict.pt in the artifact directory wins; otherwise the
+    merged model is rebuilt from bases + coefficients + the base model named in the stored config."""
+    pre = os.path.join(artifact_dir, "merged_state_dict.pt")
+    if os.path.exists(pre):
+        print(f"Loading pre-saved merged model from {pre}")
+        return torch.load(pre, map_location=device, weights_only=True)
+    print("No pre-saved merged model found, reconstructing from artifacts...")
+    config = load_config(artifact_dir)
+    base_path = getattr(config, "base_model_path", "") if not isinstance(config, dict) else config.get("base_model_path", "")
+    if not base_path or not os.path.exists(base_path):
+        raise FileNotFoundError(f"Base model path not found in config or doesn't exist: {base_path}. Please provide "
+                                "base model path in artifacts config or use reconstruct_from_artifacts instead.")
+    return reconstruct_from_artifacts(artifact_dir, base_path, None, device=device)["merged_state_dict"]

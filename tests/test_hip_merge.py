@@ -178,6 +178,17 @@ def test_artifacts_reload_end_to_end(sq, tmp_path):
     saved = torch.load(out_path, weights_only=True)
     assert torch.equal(saved["enc.w1"].cuda(), want["enc.w1"])
     assert res["config"] == cfg and "per_parameter" in res["diagnostics"]
+    # reload.py:60-139: a pre-saved merged model in the artifact directory wins; without one (and without a base
+    # model path in the stored config) the reference's error is raised
+    with pytest.raises(FileNotFoundError, match="Base model path not found"):
+        sq.reload_merged_model_from_artifacts(d, device="cuda")
+    torch.save({n: v.cpu() for n, v in want.items()}, os.path.join(d, "merged_state_dict.pt"))
+    again = sq.reload_merged_model_from_artifacts(d, device="cpu")
+    assert torch.equal(again["enc.w1"], want["enc.w1"].cpu())
+    # diagnostics.py:324-382
+    h = sq.compute_coefficient_histograms(comp["enc.w1"], sq.RTVQQuantizer(4, 2), num_bins=10, device="cuda")
+    assert set(h) == {"c_high", "c_low"} and sum(h["c_high"]["counts"]) == len(tasks) * bases["enc.w1"]["masked"]["k"]
+    assert len(h["c_low"]["bin_edges"]) == 11 and h["c_low"]["max"] >= h["c_low"]["mean"] >= 0
 
 
 # ---------------------------------------------------------------------------- cluster weighting (config #5)
