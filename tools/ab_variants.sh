@@ -2,7 +2,7 @@
 # A/B of build variants of the streaming kernels (SVDQ_LIB_PATH selects the library); prints ms/step and kernels.
 # Variants are built by hand, e.g.:  hipcc ... -DSVDQ_GRAM_TWO_CHAINS=1 -c svdq_stream.hip -o build/stream_a.o; link as var_a.so
 for cfg in "ViT-L-14 8" "ViT-B-32 8" "ViT-L-14 8" "ViT-B-32 8"; do set -- $cfg
-for v in libsvdq_hip var_a; do
+for v in libsvdq_hip var_a var_b var_c; do
   [ -f svd-quantization-task-merging_amd/$v.so ] || continue
   SVDQ_LIB_PATH=$PWD/svd-quantization-task-merging_amd/$v.so timeout -k 10 250 python bench.py --steps 20 --warmup 3 --no-cpu --model $1 --tasks $2 2>/dev/null < /dev/null | python -c "
 import sys,json
