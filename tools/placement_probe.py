@@ -34,16 +34,34 @@ def tz(x):
     return (x & -x).bit_length() - 1
 print("basis align 2^%d, mean 2^%d" % (tz(base_basis.data_ptr()), tz(base_mean.data_ptr())), flush=True)
 keep = []
-for extra in (0, 1, 2, 3, 64, 600, 1024, 2048, 0, 0):
+def fill_ms(buf, reps=3):
+    buf.fill_(1); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        buf.fill_(1)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+def read_ms(buf, reps=3):
+    v = buf.view(torch.int32)
+    v.sum(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        v.sum()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+print("original basis: fill %.4f ms, bp %.4f ms" % (fill_ms(base_basis), timed()), flush=True)
+for i in range(12):
+    extra = (i % 4) * 3
     big = torch.empty(base_basis.numel() + extra * MB, dtype=torch.uint8, device=dev)
     keep.append(big)
     plan.basis = big[:base_basis.numel()]
+    f1 = fill_ms(plan.basis)
     t1 = timed()
-    # first-touch / state effects: time again after the buffer has been fully written once by memset
-    big.zero_(); torch.cuda.synchronize()
-    t2 = timed()
-    print(f"new buffer +{extra:>5} MB at {hex(big.data_ptr())} (2^{tz(big.data_ptr())}): {t1:.4f}  after zero_: {t2:.4f}", flush=True)
+    f2 = fill_ms(plan.basis)
+    print(f"candidate {i:2d} at {hex(big.data_ptr())}: fill {f1:.4f} / {f2:.4f} ms   bp {t1:.4f} ms", flush=True)
+    if i % 3 == 2:
+        del keep[0]        # free one now and then so that later candidates reuse holes
 plan.basis = base_basis
-print("original again:", round(timed(), 4), flush=True)
-free, total = torch.cuda.mem_get_info()
-print("free GB", free / 2**30, "total", total / 2**30)
+print("original again: bp %.4f" % timed(), flush=True)
