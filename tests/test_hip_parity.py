@@ -571,6 +571,42 @@ def test_mixed_code_widths_in_one_plan(sq, orc):
     assert np.array_equal(got, singles[2].codes[1, 3, 0, :nl])
 
 
+def test_compress_is_graph_capturable(sq, orc):
+    """Nothing in svdq_compress synchronises or allocates: the launch sequence of a step can be captured into a
+    HIP graph on a side stream and replayed (same bits as the eager launches)."""
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    sizes, N = [70001, 768, 1024 * 96], 8
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 690 + i)] for i, D in enumerate(sizes)]
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=True, low_bits=4, rtvq_stages=2, device=dev)
+    eager = CompressPlan(sizes, N, **kw)
+    eager.run(eager.pointer_table(vecs))
+    torch.cuda.synchronize()
+    for flags in (0, 4):                      # the four launches, and the fused single-launch schedule
+        plan = CompressPlan(sizes, N, flags=flags, **kw)
+        table = plan.pointer_table(vecs)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            plan.run(table)                   # warm-up outside the capture
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        plan.small.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            plan.run(table)
+        assert int(plan.small.view(torch.int32).abs().sum()) == 0      # capture does not execute
+        for _ in range(2):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(plan.small, eager.small)
+        sm = eager.fetch_small()
+        for p, D in enumerate(sizes):
+            a = eager.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), D)
+            b = plan.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), D)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
 # ------------------------------------------------------------------------------- masks
 def test_masks_vs_reference_vectors(sq):
     g = load_golden("masks.npz")
