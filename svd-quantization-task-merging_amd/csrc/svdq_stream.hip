@@ -179,10 +179,26 @@ __device__ __forceinline__ void load_block_gather(f32x4 (&v)[NTP], gfloat *(&bp)
 template <int NTP, bool STRIDED = false>
 __device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int center, float *X, int lane) {
     f32x4 s = zero4();
+    if constexpr (NTP > 16) {
+        // same association as the two-wave pass 2 (each wave sums half of the tasks, then h0 + h1): pass 1 and
+        // pass 2 must centre with the same mean, bit for bit
+        f32x4 h[2];
 #pragma unroll
-    for (int t = 0; t < NTP; ++t) {
-        f32x4 x = (t < NT) ? v[t] : zero4();
-        s += x;
+        for (int w = 0; w < 2; ++w) {
+            h[w] = zero4();
+#pragma unroll
+            for (int i = 0; i < NTP / 2; ++i) {
+                const int t = w * (NTP / 2) + i;
+                h[w] += (t < NT) ? v[t] : zero4();
+            }
+        }
+        s = h[0] + h[1];
+    } else {
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+            f32x4 x = (t < NT) ? v[t] : zero4();
+            s += x;
+        }
     }
     f32x4 mean = zero4();
     if (center) {
@@ -759,7 +775,8 @@ __global__ __launch_bounds__(64) void k_basis_project(
 //   * pass 2: wave w computes the 16-column block w of U (and of the rounding-correction MFMA), so the
 //     accumulator-side registers halve as well; both stage into the same output images.
 // (A two-wave pass 1 -- each wave the full 2x2-blocked Gram over half of the sub-tiles -- was measured 10 %
-// SLOWER than the single-wave k_gram at N = 20 and is not kept.)
+// SLOWER than the single-wave k_gram at N = 20 and is not kept.  A four-wave pass 2 -- columns x row halves, a
+// quarter of the tasks loaded per wave -- is 5 % faster at N = 32 but 5 % slower at N = 20: not kept either.)
 // Barriers are s_barrier after an LDS-only wait: a full __syncthreads() would also drain the prefetch.
 __device__ __forceinline__ void wg_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
