@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--from-base", choices=("off", "fused", "ingest"), default="off",
                     help="start from fine-tuned + base weights instead of task vectors: 'fused' forms finetuned - base "
                          "inside the streaming passes (svdq_compress_from_base), 'ingest' runs svdq_ingest first")
+    ap.add_argument("--placement-candidates", type=int, default=6,
+                    help="before timing, let the plan keep the fastest of this many candidate allocations for its "
+                         "output basis (CompressPlan.tune_placement; 1 = take the first allocation as it comes)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -224,6 +227,9 @@ def main():
             itab = torch.tensor([x.data_ptr() for x in it], dtype=torch.int64).to(dev)
         rows_dev = ct
     torch.cuda.synchronize()
+    placement_ms = []
+    if mset is None and fb is None and not args.fused and args.pipeline_mb == 0 and args.placement_candidates > 1:
+        placement_ms = plan.tune_placement(table, candidates=args.placement_candidates)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
 
@@ -363,6 +369,10 @@ def main():
                                    f"{args.bits}-bit x {args.stages}-stage RTVQ",
                        "tensors_per_gpu": len(rows), "tasks": N, "mean_rank_k": round(k_mean, 2),
                        "units": int(plan.sizes.n_units), "pipeline_groups": len(groups), "schedule": "fused" if args.fused else "4 launches", "from_base": args.from_base,
+                       "output_placement": (f"fastest of {len(placement_ms)} candidate allocations for the basis, chosen "
+                                            f"before the timed region by timing pass 2 into each: "
+                                            f"{[round(x, 3) for x in placement_ms]} ms" if placement_ms
+                                            else "first allocation as it comes"),
                        "masks": args.masks, "mask_density": (round(float(sm.rows.sum()) / sumD, 4)
                                                              if args.masks != "none" else None),
                        "sharding": "none" if world == 1 else (

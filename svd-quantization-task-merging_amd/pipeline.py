@@ -217,6 +217,41 @@ class CompressPlan:
                                                    _ptr(self.workspace), _ptr(self.small), _ptr(self.basis),
                                                    _ptr(self.mean), _stream_ptr()), "svdq_compress_from_base")
 
+    def tune_placement(self, table, rows_dev=None, candidates: int = 4, reps: int = 3) -> List[float]:
+        """Pick the output allocation pass 2 runs fastest into.
+
+        On MI355X the time of ``basis_project`` depends on WHICH allocation the basis buffer lives in (2.70-3.05 ms
+        for the same inputs at ViT-L-14 x 8; not on offsets inside it, its alignment or its contiguity -- DESIGN.md
+        section 5, tools/placement_probe.py): in the slow placements the mean stream stops being free.  This times
+        the real pass 2 into ``candidates`` freshly allocated buffers (the current one included), keeps the fastest
+        and releases the others.  Call it once after the inputs are known and before results are needed: it
+        overwrites the outputs with valid results of the same inputs.  Returns the measured times in ms."""
+        if self.basis is None or candidates < 2:
+            return []
+        dev = self.device
+        with torch.cuda.device(dev):
+            self.gram_center(table, rows_dev)          # pass 2 needs W, k, r of these inputs
+            self.eig_rank_select(table, rows_dev)
+            pool = [self.basis] + [torch.empty(self.sizes.basis_bytes, dtype=torch.uint8, device=dev)
+                                   for _ in range(candidates - 1)]
+            times = []
+            for buf in pool:
+                self.basis = buf
+                self.basis_project(table, rows_dev)    # warm-up into this buffer
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    self.basis_project(table, rows_dev)
+                e1.record()
+                e1.synchronize()
+                times.append(e0.elapsed_time(e1) / reps)
+            best = min(range(len(pool)), key=lambda i: times[i])
+            self.basis = pool[best]
+            self.basis_project(table, rows_dev)
+            self.coeff_quantize()
+            torch.cuda.current_stream().synchronize()
+        return times
+
     # ---- outputs
     def fetch_small(self) -> SmallArtifacts:
         host = self.small.cpu().numpy()  # the one D2H copy (synchronises the stream)

@@ -571,6 +571,32 @@ def test_mixed_code_widths_in_one_plan(sq, orc):
     assert np.array_equal(got, singles[2].codes[1, 3, 0, :nl])
 
 
+def test_tune_placement_keeps_results(sq, orc):
+    """CompressPlan.tune_placement only changes WHERE the basis lives: same artifacts afterwards, and a later run
+    into the chosen buffer reproduces them."""
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    sizes, N = [70001, 768, 1024 * 96], 8
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 790 + i)] for i, D in enumerate(sizes)]
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=True, low_bits=4, rtvq_stages=2, device=dev)
+    ref = CompressPlan(sizes, N, **kw)
+    ref.run(ref.pointer_table(vecs))
+    plan = CompressPlan(sizes, N, **kw)
+    table = plan.pointer_table(vecs)
+    times = plan.tune_placement(table, candidates=3, reps=2)
+    assert len(times) == 3 and all(t > 0 for t in times)
+    for again in (False, True):
+        if again:
+            plan.run(table)
+        torch.cuda.synchronize()
+        assert torch.equal(plan.small, ref.small)
+        sm = ref.fetch_small()
+        for p, D in enumerate(sizes):
+            a = ref.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), D)
+            b = plan.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), D)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
 def test_compress_is_graph_capturable(sq, orc):
     """Nothing in svdq_compress synchronises or allocates: the launch sequence of a step can be captured into a
     HIP graph on a side stream and replayed (same bits as the eager launches)."""

@@ -51,17 +51,40 @@ def read_ms(buf, reps=3):
         v.sum()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-print("original basis: fill %.4f ms, bp %.4f ms" % (fill_ms(base_basis), timed()), flush=True)
-for i in range(12):
+def bp_variants():
+    full = timed()
+    m = plan.mean
+    plan.mean = None            # NULL mean pointer: pass 2 skips the mean stream
+    nomean = timed()
+    plan.mean = m
+    return full, nomean
+print("original basis: fill %.4f ms, bp %.4f / without the mean stream %.4f ms" % ((fill_ms(base_basis),) + bp_variants()), flush=True)
+for i in range(10):
     extra = (i % 4) * 3
     big = torch.empty(base_basis.numel() + extra * MB, dtype=torch.uint8, device=dev)
     keep.append(big)
     plan.basis = big[:base_basis.numel()]
-    f1 = fill_ms(plan.basis)
-    t1 = timed()
-    f2 = fill_ms(plan.basis)
-    print(f"candidate {i:2d} at {hex(big.data_ptr())}: fill {f1:.4f} / {f2:.4f} ms   bp {t1:.4f} ms", flush=True)
-    if i % 3 == 2:
-        del keep[0]        # free one now and then so that later candidates reuse holes
+    full, nomean = bp_variants()
+    print(f"candidate {i:2d} at {hex(big.data_ptr())}: bp {full:.4f} ms   without the mean stream {nomean:.4f} ms", flush=True)
 plan.basis = base_basis
+mean0 = plan.mean
+for i in range(6):
+    mm = torch.empty(mean0.numel() + (i % 3) * MB, dtype=torch.float32, device=dev)
+    keep.append(mm)
+    plan.mean = mm[:mean0.numel()]
+    print(f"mean candidate {i} at {hex(mm.data_ptr())}: bp {timed():.4f} ms", flush=True)
+plan.mean = mean0
+# one allocation holding both outputs: basis first, mean behind it at a few different distances
+nb = base_basis.numel()
+nm = mean0.numel() * 4
+for i in range(10):
+    pad = (0, 256, 4096, 1 << 20, 3 << 20)[i % 5]
+    off = (nb + 255) // 256 * 256 + pad
+    both = torch.empty(off + nm + (i // 5) * 5 * MB, dtype=torch.uint8, device=dev)
+    keep.append(both)
+    plan.basis = both[:nb]
+    plan.mean = both[off:off + nm].view(torch.float32)
+    print(f"joint candidate {i:2d} at {hex(both.data_ptr())} pad {pad:>8}: bp {timed():.4f} ms", flush=True)
+plan.basis = base_basis
+plan.mean = mean0
 print("original again: bp %.4f" % timed(), flush=True)
