@@ -228,7 +228,8 @@ def main():
         rows_dev = ct
     torch.cuda.synchronize()
     placement_ms = []
-    if mset is None and fb is None and not args.fused and args.pipeline_mb == 0 and args.placement_candidates > 1:
+    if not args.fused and args.pipeline_mb == 0 and args.placement_candidates > 1:
+        # (masked / from-base runs: the probe uses the plain pass 2 on the full-size tensors; it ranks allocations)
         placement_ms = plan.tune_placement(table, candidates=args.placement_candidates)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
