@@ -338,7 +338,8 @@ def basis_dict(plan: CompressPlan, sm: SmallArtifacts, p: int) -> Dict:
     """construct_basis return layout (reference basis.py:398-407)."""
     k, r, rows = int(sm.k[p]), int(sm.r[p]), int(sm.rows[p])
     U_high, U_low, mean = plan.basis_tensors(p, k, r, rows)
-    S = torch.from_numpy(sm.sigma[p, :r].copy()).to(plan.device)
+    off = plan.layout.sigma_off + p * plan.N * 4       # zero-copy view of the device copy (no per-parameter H2D)
+    S = plan.small[off:off + r * 4].view(torch.float32)
     return {"U_high": U_high, "U_low": U_low, "singular_values": S, "k": k, "mean": mean,
             "energy_retained": float(sm.energy[p]), "D": rows, "N": plan.N}
 
