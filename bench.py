@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--masks", choices=("none", "union", "intersection", "majority"), default="none",
                     help="BASELINE configs[2]: per-task tall masks (rand > 0.7) combined on device; the four stages "
                          "then read every task tensor through the combined mask's index list (gather mode)")
+    ap.add_argument("--masks-packed", action="store_true",
+                    help="hand the per-task masks over bit-packed (numpy.packbits order, the form TALL_mask files have)")
     ap.add_argument("--masks-compact", action="store_true",
                     help="A/B: materialise compacted copies of the deltas (the pre-gather schedule) instead")
     ap.add_argument("--from-base", choices=("off", "fused", "ingest"), default="off",
@@ -219,7 +221,24 @@ def main():
         per_task = [[torch.rand(r, device=dev, generator=gm) > 0.7 for _ in range(N)] for r in rows]
         mset = MaskSet(rows, dev)
         comb, counts = mset.prepare_combine(per_task, args.masks)
-        if args.masks_compact:
+        if args.masks_packed:
+            # one bit stream per task over the concatenated parameters (first element = most significant bit)
+            wts = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8, device=dev)
+            streams = []
+            for t in range(N):
+                bits = torch.cat([per_task[p][t] for p in range(len(rows))])
+                pad = (-bits.numel()) % 8
+                if pad:
+                    bits = torch.cat([bits, torch.zeros(pad, dtype=torch.bool, device=dev)])
+                streams.append((bits.view(-1, 8).to(torch.uint8) * wts).sum(dim=1, dtype=torch.uint8))
+            offs, acc = [], 0
+            for r in rows:
+                offs.append(acc)
+                acc += r
+            comb, it, _, ct, _ = mset.prepare_combine_packed_indices(streams, offs, args.masks, want_false=False)
+            itab = torch.tensor([x.data_ptr() for x in it], dtype=torch.int64).to(dev)
+            del per_task
+        elif args.masks_compact:
             dt, _, ct, _ = mset.prepare_compact([c.view(torch.bool) for c in comb], views, want_false=False)
             table = plan.pointer_table(dt)
         else:
@@ -279,6 +298,9 @@ def main():
                 mset.run_combine()
                 mset.run_compact()
                 plan.run(table, rows_dev)
+            elif args.masks_packed:
+                mset.run_combine_packed_indices()
+                plan.run_gather(table, itab, rows_dev)
             else:
                 mset.run_combine_indices()
                 plan.run_gather(table, itab, rows_dev)

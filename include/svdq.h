@@ -292,6 +292,18 @@ int     svdq_maskset_combine_indices(const svdq_maskset *ms, const void *mask_pt
                                      const void *idx_false_ptrs_dev, int64_t *count_true_dev,
                                      int64_t *count_false_dev, void *work_dev, void *stream);
 
+/* The same from BIT-PACKED tall masks, the form the reference's mask files have (load_tall_mask_file,
+ * mask_loader.py:125-206: one numpy.packbits stream per task over the flattened state dict, first element = most
+ * significant bit): stream_ptrs_dev [n_masks] device streams, stream_bytes_dev [n_masks] their lengths,
+ * bit_offsets_dev [n_params] the bit position of each parameter's first element inside every stream.  Reads
+ * n_masks / 8 bytes per element instead of n_masks; writes the combined bool masks, index lists and counts. */
+int     svdq_maskset_combine_packed_indices(const svdq_maskset *ms, const void *stream_ptrs_dev,
+                                            const int64_t *stream_bytes_dev, const int64_t *bit_offsets_dev,
+                                            int32_t n_masks, int32_t strategy, const void *out_ptrs_dev,
+                                            const void *idx_true_ptrs_dev, const void *idx_false_ptrs_dev,
+                                            int64_t *count_true_dev, int64_t *count_false_dev, void *work_dev,
+                                            void *stream);
+
 /* ---- merge consumers (the parity reconstruction of R14)
  *      svdq_reconstruct: reconstruct_from_coefficients (merge.py:144-194):
  *        out[d] = ((sum_i U_high[d][i] c[i] + sum_j U_low[d][j] c[k+j]) + mean[d]) * scale

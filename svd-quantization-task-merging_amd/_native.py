@@ -82,6 +82,8 @@ SIGNATURES = {
     "svdq_maskset_indices": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_maskset_combine_indices": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_maskset_combine_packed_indices": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
+                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_compress_gather": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
     "svdq_compress_from_base": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1079,6 +1079,128 @@ extern "C" int svdq_maskset_combine_indices(const svdq_maskset *ms, const void *
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
+// Tall masks as they are distributed (mask_loader.py:125-206): ONE bit per element of the flattened state dict,
+// numpy.packbits order (first element = most significant bit), one stream per task.  Combining them from the
+// packed form reads N/8 bytes per element instead of N: parameter q's elements are bits bit_off[q] + e of every
+// stream.  Output: the combined mask as bool bytes (what the reference hands on), tile counts for the index build.
+__global__ __launch_bounds__(ELT_THREADS) void k_maskset_combine_packed(const int32_t *__restrict__ tile_param,
+                                                                        const int32_t *__restrict__ tile_begin,
+                                                                        const int64_t *__restrict__ numel_tab,
+                                                                        const uint8_t *const *__restrict__ streams,
+                                                                        const int64_t *__restrict__ bit_off,
+                                                                        const int64_t *__restrict__ stream_bytes,
+                                                                        int n_masks, int strategy,
+                                                                        uint8_t *const *__restrict__ outs,
+                                                                        unsigned *__restrict__ tile_counts) {
+    // the tile's packed bytes of every stream are fetched with 16-byte loads into LDS first (17 chunks cover the 257
+    // bytes a 2048-element tile can touch at an arbitrary bit offset); byte loads per thread would waste the bus
+    __shared__ __attribute__((aligned(16))) uint8_t S[SVDQ_MAX_TASKS][17 * 16];
+    const int q = tile_param[blockIdx.x];
+    const int64_t numel = numel_tab[q];
+    const int64_t tile0 = (int64_t)(blockIdx.x - tile_begin[q]) * MASK_TILE;
+    const int64_t base = tile0 + (int64_t)threadIdx.x * 8;
+    const int64_t c0 = ((bit_off[q] + tile0) >> 3) & ~(int64_t)15;   // first 16-byte chunk of this tile in every stream
+    for (int i = threadIdx.x; i < n_masks * 17; i += ELT_THREADS) {
+        const int m = i / 17, c = i - m * 17;
+        const int64_t b = c0 + 16 * c;
+        const int64_t nb = stream_bytes[m];
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (b + 16 <= nb) {
+            v = *reinterpret_cast<const uint4 *>(streams[m] + b);
+        } else if (b < nb) {
+            uint8_t tmp[16];
+            for (int k = 0; k < 16; ++k) tmp[k] = (b + k < nb) ? streams[m][b + k] : (uint8_t)0;
+            v = *reinterpret_cast<const uint4 *>(tmp);
+        }
+        *reinterpret_cast<uint4 *>(&S[m][16 * c]) = v;
+    }
+    __syncthreads();
+    unsigned cnt = 0;
+    if (base < numel) {
+        const int lim = (int)((numel - base) < 8 ? (numel - base) : 8);
+        const int64_t pos = bit_off[q] + base;   // bit position of this thread's first element in every stream
+        const int byte = (int)((pos >> 3) - c0);
+        const int sh = (int)(pos & 7);
+        unsigned char cnts[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cnts[j] = 0;
+        unsigned any = 0, all = 0xff;
+        for (int m = 0; m < n_masks; ++m) {
+            const unsigned w = ((unsigned)S[m][byte] << 8) | S[m][byte + 1];   // byte + 1 <= 16 * 17 - 1: in the image
+            const unsigned bits = (w >> (8 - sh)) & 0xff;   // 8 elements, first element = bit 7
+            any |= bits;
+            all &= bits;
+            if (strategy == SVDQ_MASK_MAJORITY) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cnts[j] += (bits >> (7 - j)) & 1;
+            }
+        }
+        unsigned long long res = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned bit;
+            if (strategy == SVDQ_MASK_UNION)
+                bit = (any >> (7 - j)) & 1;
+            else if (strategy == SVDQ_MASK_INTERSECTION)
+                bit = (all >> (7 - j)) & 1;
+            else
+                bit = 2 * cnts[j] >= n_masks;
+            if (j < lim) res |= (unsigned long long)bit << (8 * j);
+        }
+        uint8_t *out = outs[q];
+        if (lim == 8 && (reinterpret_cast<uintptr_t>(out + base) & 7) == 0) {
+            *reinterpret_cast<unsigned long long *>(out + base) = res;
+        } else {
+            for (int j = 0; j < lim; ++j) out[base + j] = (uint8_t)((res >> (8 * j)) & 1);
+        }
+        cnt = (unsigned)__popcll(res);
+    }
+    const unsigned tot = block_sum_u32(cnt);
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+}
+
+extern "C" int svdq_maskset_combine_packed_indices(const svdq_maskset *ms, const void *stream_ptrs,
+                                                   const int64_t *stream_bytes, const int64_t *bit_offsets,
+                                                   int32_t n_masks, int32_t strategy, const void *out_ptrs,
+                                                   const void *idx_true_ptrs, const void *idx_false_ptrs,
+                                                   int64_t *count_true, int64_t *count_false, void *work,
+                                                   void *stream) {
+    if (!ms || !stream_ptrs || !stream_bytes || !bit_offsets || !out_ptrs || !idx_true_ptrs || !count_true || !work ||
+        n_masks < 1) {
+        svdq_set_error(n_masks < 1 ? "Empty mask list" : "svdq_maskset_combine_packed_indices: bad argument");
+        return SVDQ_EINVAL;
+    }
+    if (n_masks > SVDQ_MAX_TASKS) {
+        svdq_set_error("at most %d packed mask streams are supported, got %d", SVDQ_MAX_TASKS, n_masks);
+        return SVDQ_EINVAL;
+    }
+    if (strategy < 0 || strategy > 2) {
+        svdq_set_error("Unknown mask strategy: %d", strategy);
+        return SVDQ_EINVAL;
+    }
+    for (int q = 0; q < ms->n_params; ++q)
+        if (ms->h_numel[q] > 0x7fffffffLL) {
+            svdq_set_error("svdq_maskset_combine_packed_indices: parameter %d has more than 2^31-1 elements", q);
+            return SVDQ_EUNSUPPORTED;
+        }
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *wb = reinterpret_cast<uint8_t *>(work);
+    unsigned *tile_counts = reinterpret_cast<unsigned *>(wb);
+    unsigned long long *tile_offsets =
+        reinterpret_cast<unsigned long long *>(wb + svdq_align_up((int64_t)ms->n_tiles * 4, 256));
+    hipLaunchKernelGGL(k_maskset_combine_packed, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param,
+                       ms->d_tile_begin, ms->d_numel, reinterpret_cast<const uint8_t *const *>(stream_ptrs), bit_offsets,
+                       stream_bytes, n_masks, strategy, reinterpret_cast<uint8_t *const *>(out_ptrs), tile_counts);
+    hipLaunchKernelGGL(k_maskset_scan, dim3(ms->n_params), dim3(1024), 0, st, ms->d_tile_begin, ms->d_numel, tile_counts,
+                       tile_offsets, reinterpret_cast<long long *>(count_true),
+                       reinterpret_cast<long long *>(count_false));
+    hipLaunchKernelGGL(k_maskset_index, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
+                       ms->d_numel, reinterpret_cast<const uint8_t *const *>(out_ptrs),
+                       reinterpret_cast<int32_t *const *>(idx_true_ptrs),
+                       reinterpret_cast<int32_t *const *>(idx_false_ptrs), tile_offsets);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
 // ------------------------------------------------------------------------------------ diagnostics
 // compute_reconstruction_error (diagnostics.py:72-117) fused with the reconstruction it is applied to in
 // compute_parameter_diagnostics (diagnostics.py:205-215): rec = U_high c_high + U_low c_low (+ mean when

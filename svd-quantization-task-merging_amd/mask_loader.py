@@ -144,6 +144,38 @@ class MaskSet:
                                                             _ptr(self.work), _stream_ptr()),
                       "svdq_maskset_combine_indices")
 
+    def prepare_combine_packed_indices(self, streams, bit_offsets, strategy: str, want_false: bool):
+        """Combine + index build straight from BIT-PACKED tall masks (numpy.packbits order, one uint8 stream per
+        task over the flattened state dict -- the form TALL_mask files have): parameter q's elements are bits
+        ``bit_offsets[q] + e`` of every stream.  Returns (combined bool-byte masks, idx_true, idx_false | None,
+        count_true, count_false | None); run with run_combine_packed_indices()."""
+        if strategy not in nat.MASK_STRATEGIES:
+            raise ValueError(f"Unknown mask strategy: {strategy}")
+        if not streams:
+            raise ValueError("Empty mask list")
+        st = [s.to(self.device).contiguous().view(torch.uint8) for s in streams]
+        need = max((int(o) + n + 7) // 8 for o, n in zip(bit_offsets, self.numels))
+        if any(s.numel() < need for s in st):
+            raise ValueError("Shape mismatch: a packed mask stream is shorter than the parameters it should cover")
+        outs = [torch.empty(nq, dtype=torch.uint8, device=self.device) for nq in self.numels]
+        it = [torch.empty(nq, dtype=torch.int32, device=self.device) for nq in self.numels]
+        if_ = [torch.empty(nq, dtype=torch.int32, device=self.device) for nq in self.numels] if want_false else None
+        ct = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        cf = torch.zeros(self.Q, dtype=torch.int64, device=self.device) if want_false else None
+        self._p = dict(st=st, outs=outs, it=it, if_=if_, ct=ct, cf=cf, n=len(st), strategy=nat.MASK_STRATEGIES[strategy],
+                       sp=self._table(st), sb=torch.tensor([s.numel() for s in st], dtype=torch.int64).to(self.device),
+                       bo=torch.tensor([int(o) for o in bit_offsets], dtype=torch.int64).to(self.device),
+                       ot=self._table(outs), tt=self._table(it), ft=self._table(if_) if want_false else None)
+        return outs, it, if_, ct, cf
+
+    def run_combine_packed_indices(self):
+        x = self._p
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_combine_packed_indices(
+                self._h, _ptr(x["sp"]), _ptr(x["sb"]), _ptr(x["bo"]), x["n"], x["strategy"], _ptr(x["ot"]), _ptr(x["tt"]),
+                _ptr(x["ft"]), _ptr(x["ct"]), _ptr(x["cf"]), _ptr(self.work), _stream_ptr()),
+                "svdq_maskset_combine_packed_indices")
+
     def indices(self, masks, want_false: bool):
         """Ascending flat positions (int32) of the set / cleared elements of every mask: what the gather mode
         of the compressor reads the task deltas through, instead of 2 N compacted copies per parameter.

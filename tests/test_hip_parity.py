@@ -633,6 +633,35 @@ def test_compress_is_graph_capturable(sq, orc):
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
+@pytest.mark.parametrize("strategy", ["union", "intersection", "majority"])
+def test_packed_tall_masks_equal_unpacked(sq, strategy):
+    """Combining tall masks from their numpy.packbits form (one stream per task over the flattened state dict,
+    parameters at arbitrary bit offsets) gives exactly the masks, index lists and counts of the bool-tensor route."""
+    from svdq_amd.mask_loader import MaskSet
+    dev = torch.device("cuda", 0)
+    sizes = [300001, 777, 2048 * 5 + 3, 12, 70000]
+    n_tasks = 5
+    rng = np.random.default_rng(29)
+    flat = [rng.random(sum(sizes)) > 0.6 for _ in range(n_tasks)]             # one flattened mask per task
+    streams = [torch.from_numpy(np.packbits(m)).to(dev) for m in flat]         # what a TALL_mask file holds
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
+    per_task = [[torch.from_numpy(flat[t][o:o + n]).to(dev) for t in range(n_tasks)] for o, n in zip(offs, sizes)]
+    a = MaskSet(sizes, dev)
+    outs, it, if_, ct, cf = a.prepare_combine_indices(per_task, strategy, want_false=True)
+    a.run_combine_indices()
+    b = MaskSet(sizes, dev)
+    outs2, it2, if2, ct2, cf2 = b.prepare_combine_packed_indices(streams, offs, strategy, want_false=True)
+    b.run_combine_packed_indices()
+    torch.cuda.synchronize()
+    assert torch.equal(ct, ct2) and torch.equal(cf, cf2)
+    for q, D in enumerate(sizes):
+        n = int(ct[q])
+        assert torch.equal(outs[q], outs2[q])
+        assert torch.equal(it[q][:n], it2[q][:n]) and torch.equal(if_[q][:D - n], if2[q][:D - n])
+    with pytest.raises(ValueError, match="shorter than the parameters"):
+        b.prepare_combine_packed_indices([s[:100] for s in streams], offs, strategy, want_false=False)
+
+
 # ------------------------------------------------------------------------------- masks
 def test_masks_vs_reference_vectors(sq):
     g = load_golden("masks.npz")
