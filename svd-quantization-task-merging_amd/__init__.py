@@ -19,7 +19,8 @@ from .compress import (project_to_basis, compress_single_task, compress_masked_r
                        compress_all_parameters)
 from .mask_loader import (combine_masks, compute_union_mask, compute_intersection_mask, compute_majority_mask,
                           apply_mask_to_tensor, get_unmasked_portion, reconstruct_from_masked, load_task_masks,
-                          load_single_mask, load_tall_mask_file, state_dict_to_vector, vector_to_state_dict)
+                          load_single_mask, load_tall_mask_file, state_dict_to_vector, vector_to_state_dict,
+                          combine_tall_masks_packed)
 from .merge import (dequantize_and_average, reconstruct_from_coefficients, merge_parameter, merge_all_parameters,
                     apply_merged_deltas, merge_with_clustering)
 from .weighting import (load_performance_metrics, compute_uniform_weights, compute_performance_weights,

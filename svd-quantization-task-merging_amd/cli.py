@@ -28,12 +28,23 @@ from .config import SVDHybridConfig
 from .diagnostics import (compute_all_diagnostics, compute_compression_statistics, print_detailed_compression_report,
                           print_diagnostics_summary)
 from .driver import run_basis_and_compress
-from .mask_loader import combine_masks, load_task_masks
+from .mask_loader import combine_masks, combine_tall_masks_packed, load_task_masks
 from .merge import apply_merged_deltas, merge_all_parameters, merge_with_clustering
 from .pipeline import resolve_device
 from .storage import save_all_artifacts, save_merged_model
 from .task_vector_loader import (get_parameter_names, get_task_checkpoint_paths, load_checkpoint, load_task_vectors)
 from .weighting import compute_weights
+
+
+def _find_tall_mask_file(mask_dir: str, n_tasks: int):
+    """The reference's TALL mask file names (mask_loader.py:303-320), plus the .npz / .pt containers this package reads."""
+    for stem in (f"TALL_mask_{n_tasks}task", f"TALL_mask_{n_tasks}tasks", f"tall_mask_{n_tasks}task",
+                 f"tall_mask_{n_tasks}tasks"):
+        for ext in (".npy", ".npz", ".pt"):
+            path = os.path.join(mask_dir, stem + ext)
+            if os.path.exists(path):
+                return path
+    return None
 
 
 def run_svd_hybrid_pipeline(config: SVDHybridConfig) -> Dict:
@@ -50,8 +61,14 @@ def run_svd_hybrid_pipeline(config: SVDHybridConfig) -> Dict:
     combined_masks: Dict[str, torch.Tensor] = {}
     if config.mask_dir and os.path.exists(config.mask_dir):
         print(f"[2/8] loading masks from {config.mask_dir} (strategy: {config.svd_mask_strategy})")
-        task_masks = load_task_masks(config.mask_dir, config.tasks, device=device, reference_state_dict=base_state_dict)
-        combined_masks = combine_masks(task_masks, strategy=config.svd_mask_strategy, device=device, verbose=False)
+        tall = _find_tall_mask_file(config.mask_dir, len(config.tasks))
+        if tall is not None:     # bit-packed tall masks: combined on the GPU straight from the packed streams
+            float_ref = {k: v for k, v in base_state_dict.items() if isinstance(v, torch.Tensor)}
+            combined_masks = combine_tall_masks_packed(tall, config.tasks, float_ref, config.svd_mask_strategy, device)
+        else:
+            task_masks = load_task_masks(config.mask_dir, config.tasks, device=device,
+                                         reference_state_dict=base_state_dict)
+            combined_masks = combine_masks(task_masks, strategy=config.svd_mask_strategy, device=device, verbose=False)
     else:
         print("[2/8] no masks")
 

@@ -440,3 +440,67 @@ def load_task_masks(mask_dir: str, task_names: List[str], device: str = "cpu",
         if verbose and out[t] is None:
             print(f"   no mask file for task {t}")
     return out
+
+
+def _read_packed_tall_masks(mask_path: str) -> Dict[str, "torch.Tensor"]:
+    """{task: uint8 packed stream} from an .npz (numpy.load) or a torch file of uint8 tensors -- loaders that
+    execute nothing from the file."""
+    import numpy as np
+    packed = None
+    try:
+        z = np.load(mask_path, allow_pickle=False)
+        if hasattr(z, "files"):
+            packed = {k: z[k] for k in z.files}
+    except Exception:
+        packed = None
+    if packed is None:
+        try:
+            packed = torch.load(mask_path, map_location="cpu", weights_only=True)
+        except Exception as e:
+            raise RuntimeError(f"{mask_path}: not loadable without unpickling arbitrary objects ({e}); "
+                               "convert it with numpy.savez(path, **packed_masks)") from e
+    out = {}
+    for task, pm in packed.items():
+        t = pm if isinstance(pm, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pm))
+        if t.dtype != torch.uint8:
+            raise TypeError(f"Unexpected type for packed_mask: {t.dtype}")
+        out[task] = t.reshape(-1)
+    return out
+
+
+def combine_tall_masks_packed(mask_path: str, task_names: List[str], reference_state_dict: Dict[str, torch.Tensor],
+                              strategy: str = "union", device="cuda", remove_keys: Optional[List[str]] = None
+                              ) -> Dict[str, torch.Tensor]:
+    """load_tall_mask_file + combine_masks (mask_loader.py:125-206, 488-648) without ever unpacking on the host:
+    the bit-packed per-task streams go to the GPU as they are and ``svdq_maskset_combine_packed_indices`` votes on
+    them in place (parameters = sorted keys of the reference state dict, each at its bit offset in the stream).
+    Tasks missing from the file are skipped, as tasks with ``None`` masks are in combine_masks.
+    Returns {parameter: combined bool mask on the GPU, shaped like the parameter}."""
+    if strategy not in nat.MASK_STRATEGIES:
+        raise ValueError(f"Unknown mask strategy: {strategy}")
+    dev = resolve_device(device)
+    packed = _read_packed_tall_masks(mask_path)
+    streams = [packed[t] for t in task_names if t in packed]
+    if not streams:
+        return {}
+    skip = set(remove_keys or [])
+    keys = [k for k in sorted(reference_state_dict.keys()) if k not in skip]
+    sizes = [reference_state_dict[k].numel() for k in keys]
+    offs, acc = [], 0
+    for n in sizes:
+        offs.append(acc)
+        acc += n
+    live = [i for i, n in enumerate(sizes) if n > 0]
+    out: Dict[str, torch.Tensor] = {k: torch.zeros(reference_state_dict[k].shape, dtype=torch.bool, device=dev)
+                                    for k, n in zip(keys, sizes) if n == 0}
+    if live:
+        with torch.cuda.device(dev):
+            ms = MaskSet([sizes[i] for i in live], dev)
+            outs, _, _, _, _ = ms.prepare_combine_packed_indices(streams, [offs[i] for i in live], strategy,
+                                                                 want_false=False)
+            ms.run_combine_packed_indices()
+            torch.cuda.current_stream().synchronize()
+            ms.close()
+        for i, o in zip(live, outs):
+            out[keys[i]] = o.view(torch.bool).view(reference_state_dict[keys[i]].shape)
+    return {k: out[k] for k in keys}

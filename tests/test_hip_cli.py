@@ -126,3 +126,37 @@ def test_compression_statistics_vs_reference(sq):
     got = sq.compute_compression_statistics(tv, comp, bases, cfg)
     ref = json.loads(str(gc["compression_stats_json"]))
     assert json.loads(json.dumps(got, sort_keys=True)) == ref
+
+
+@pytest.mark.parametrize("strategy", ["union", "majority"])
+def test_packed_tall_mask_file_route(sq, tmp_path, strategy):
+    """A TALL_mask_{N}task file (bit-packed per-task masks over the flattened, key-sorted state dict): the packed
+    GPU route equals load_tall_mask_file + combine_masks, and the command line picks it up."""
+    tasks = ["Cars", "DTD", "EuroSAT", "GTSRB", "MNIST", "SVHN"]
+    base, shapes, deltas = _write_checkpoints(tmp_path, tasks, with_masks=False)
+    keys = sorted(base.keys())
+    total = sum(base[k].numel() for k in keys)
+    rng = np.random.default_rng(3)
+    packed = {t: np.packbits(rng.random(total) > 0.55) for t in tasks}
+    md = tmp_path / "tall"
+    md.mkdir()
+    np.savez(md / f"TALL_mask_{len(tasks)}task.npz", **packed)
+    path = str(md / f"TALL_mask_{len(tasks)}task.npz")
+    per_task = sq.load_tall_mask_file(path, base, device="cuda")
+    want = sq.combine_masks({t: per_task[t] for t in tasks}, strategy=strategy, device="cuda", verbose=False)
+    got = sq.combine_tall_masks_packed(path, tasks, base, strategy, "cuda")
+    assert sorted(got) == sorted(want) == keys
+    for k in keys:
+        assert got[k].shape == base[k].shape and got[k].dtype == torch.bool
+        assert torch.equal(got[k], want[k].to(got[k].device)), k
+    # a task the file does not contain is skipped (combine_masks skips tasks whose masks are None)
+    got5 = sq.combine_tall_masks_packed(path, tasks[:5] + ["Unknown"], base, strategy, "cuda")
+    want5 = sq.combine_masks({t: per_task[t] for t in tasks[:5]}, strategy=strategy, device="cuda", verbose=False)
+    assert all(torch.equal(got5[k], want5[k].to(got5[k].device)) for k in keys)
+    out, art = tmp_path / "out", tmp_path / "art"
+    res = sq.cli.main(["--tasks", *tasks, "--checkpoint-dir", str(tmp_path / "ckpt"), "--base-model-path",
+                       str(tmp_path / "base.pt"), "--mask-dir", str(md), "--mask-strategy", strategy,
+                       "--energy-threshold", "0.9", "--max-rank", "2", "--output-dir", str(out), "--artifact-dir", str(art)])
+    for k, s in shapes.items():
+        b = res["bases"][k]["masked"]
+        assert b["D"] == int(want[k].sum()) and b["U_high"].shape[0] == b["D"]
