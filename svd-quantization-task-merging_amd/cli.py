@@ -27,7 +27,7 @@ from .clustering import cluster_tasks, get_cluster_members
 from .config import SVDHybridConfig
 from .diagnostics import (compute_all_diagnostics, compute_compression_statistics, print_detailed_compression_report,
                           print_diagnostics_summary)
-from .driver import run_basis_and_compress
+from .driver import run_basis_and_compress, run_basis_and_compress_from_checkpoints
 from .mask_loader import combine_masks, combine_tall_masks_packed, load_task_masks
 from .merge import apply_merged_deltas, merge_all_parameters, merge_with_clustering
 from .pipeline import resolve_device
@@ -53,10 +53,23 @@ def run_svd_hybrid_pipeline(config: SVDHybridConfig) -> Dict:
     print(f"[1/8] loading base model and {len(config.tasks)} task checkpoints")
     base_state_dict = load_checkpoint(config.base_model_path, device="cpu")
     paths = get_task_checkpoint_paths(config.checkpoint_dir, config.tasks)
-    task_vectors = load_task_vectors(config.base_model_path, paths, device=device)
-    # the merge is defined on floating-point parameters; integer buffers (step counters ...) are carried over
-    task_vectors = {t: {k: v for k, v in tv.items() if base_state_dict[k].is_floating_point()}
-                    for t, tv in task_vectors.items()}
+    has_masks = bool(config.mask_dir) and os.path.exists(config.mask_dir)
+    # Nothing downstream needs the task vectors themselves when there are no masks, no clustering and no
+    # reconstruction diagnostics: then finetuned - base is formed inside the two streaming passes
+    # (svdq_compress_from_base) and the deltas are never materialised.
+    from_checkpoints = (not has_masks) and config.svd_weighting != "cluster" and not config.svd_eval_reconstruction
+    if from_checkpoints:
+        float_base = {k: v for k, v in base_state_dict.items() if isinstance(v, torch.Tensor) and v.is_floating_point()}
+        task_vectors = {}
+        for t, pth in paths.items():
+            print(f"Loading fine-tuned weights for {t} from {pth}")
+            sd = load_checkpoint(pth, device="cpu")
+            task_vectors[t] = {k: v for k, v in sd.items() if k in float_base and v.shape == float_base[k].shape}
+    else:
+        task_vectors = load_task_vectors(config.base_model_path, paths, device=device)
+        # the merge is defined on floating-point parameters; integer buffers (step counters ...) are carried over
+        task_vectors = {t: {k: v for k, v in tv.items() if base_state_dict[k].is_floating_point()}
+                        for t, tv in task_vectors.items()}
 
     combined_masks: Dict[str, torch.Tensor] = {}
     if config.mask_dir and os.path.exists(config.mask_dir):
@@ -80,7 +93,10 @@ def run_svd_hybrid_pipeline(config: SVDHybridConfig) -> Dict:
     print(f"[3/8] {len(param_names)} parameters, {sum(s.numel() for s in original_shapes.values()):,} elements")
 
     print("[4-5/8] bases + compression (svdq_compress)")
-    bases, compressed_all = run_basis_and_compress(task_vectors, combined_masks, config, device)
+    if from_checkpoints:   # task_vectors holds the fine-tuned weights here (same names and shapes as the deltas)
+        bases, compressed_all = run_basis_and_compress_from_checkpoints(float_base, task_vectors, config, device)
+    else:
+        bases, compressed_all = run_basis_and_compress(task_vectors, combined_masks, config, device)
     stats = compute_compression_statistics(task_vectors, compressed_all, bases, config)
     print_detailed_compression_report(stats, config)
 

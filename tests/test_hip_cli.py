@@ -160,3 +160,22 @@ def test_packed_tall_mask_file_route(sq, tmp_path, strategy):
     for k, s in shapes.items():
         b = res["bases"][k]["masked"]
         assert b["D"] == int(want[k].sum()) and b["U_high"].shape[0] == b["D"]
+
+
+def test_cli_from_checkpoints_route_matches(sq, tmp_path):
+    """--no-eval-reconstruction without masks or clustering: the driver compresses straight from the fine-tuned and
+    base weights (no task vectors in HBM); the merged model is the same, bit for bit, as on the ordinary route."""
+    tasks = ["Cars", "DTD", "EuroSAT", "GTSRB", "MNIST", "SVHN"]
+    base, shapes, deltas = _write_checkpoints(tmp_path, tasks, with_masks=False)
+    common = ["--tasks", *tasks, "--checkpoint-dir", str(tmp_path / "ckpt"), "--base-model-path", str(tmp_path / "base.pt"),
+              "--energy-threshold", "0.9", "--max-rank", "2", "--store-artifacts"]
+    a = sq.cli.main(common + ["--output-dir", str(tmp_path / "o1"), "--artifact-dir", str(tmp_path / "a1")])
+    b = sq.cli.main(common + ["--no-eval-reconstruction", "--output-dir", str(tmp_path / "o2"), "--artifact-dir",
+                              str(tmp_path / "a2")])
+    assert "summary" in a["diagnostics"] and list(b["diagnostics"].keys()) == ["task_weights"]
+    assert set(a["merged_state_dict"]) == set(b["merged_state_dict"])
+    for k in a["merged_state_dict"]:
+        assert torch.equal(a["merged_state_dict"][k].cpu(), b["merged_state_dict"][k].cpu()), k
+    for k in shapes:
+        assert torch.equal(a["bases"][k]["masked"]["U_low"], b["bases"][k]["masked"]["U_low"])
+    assert a["compression_statistics"]["summary"] == b["compression_statistics"]["summary"]
