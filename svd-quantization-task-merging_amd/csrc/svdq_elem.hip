@@ -970,7 +970,7 @@ __device__ __forceinline__ unsigned block_scan_u32(unsigned v, unsigned *total) 
 // Index lists for the gather mode of the streaming passes (svdq_compress_gather): the ascending flat positions
 // of the selected (and, when asked, of the unselected) elements of every parameter.  Same tile scan as the
 // compaction; 4 B written per element instead of 4 N B read + 4 N B written.
-__global__ __launch_bounds__(ELT_THREADS) void k_maskset_index(const int32_t *__restrict__ tile_param,
+__device__ void maskset_index_tile(int gtile, const int32_t *__restrict__ tile_param,
                                                                const int32_t *__restrict__ tile_begin,
                                                                const int64_t *__restrict__ numel_tab,
                                                                const uint8_t *const *__restrict__ masks,
@@ -978,8 +978,8 @@ __global__ __launch_bounds__(ELT_THREADS) void k_maskset_index(const int32_t *__
                                                                int32_t *const *__restrict__ idx_false,
                                                                const unsigned long long *__restrict__ tile_offsets) {
     __shared__ int32_t lt[MASK_TILE], lf[MASK_TILE];
-    const int q = tile_param[blockIdx.x];
-    const int64_t tile = blockIdx.x - tile_begin[q], numel = numel_tab[q];
+    const int q = tile_param[gtile];
+    const int64_t tile = gtile - tile_begin[q], numel = numel_tab[q];
     const uint8_t *mask = masks[q];
     const int tid = threadIdx.x;
     const int64_t tbase = tile * MASK_TILE;
@@ -1005,12 +1005,31 @@ __global__ __launch_bounds__(ELT_THREADS) void k_maskset_index(const int32_t *__
         }
     }
     __syncthreads();
-    const unsigned long long t_off = tile_offsets[blockIdx.x];
+    const unsigned long long t_off = tile_offsets[gtile];
     int32_t *dt = idx_true[q] + t_off;
     for (unsigned i = tid; i < tot_true; i += ELT_THREADS) dt[i] = lt[i];
     if (idx_false) {
         int32_t *df = idx_false[q] + ((unsigned long long)tbase - t_off);
         for (unsigned i = tid; i < tot_false; i += ELT_THREADS) df[i] = lf[i];
+    }
+    __syncthreads();   // the LDS images are reused by the block's next tile
+}
+
+// MASK_TPB consecutive tiles per block: these kernels do a few hundred bytes of work per thread and tile, so the
+// block start-up dominates when every tile is its own block
+#define MASK_TPB 4
+__global__ __launch_bounds__(ELT_THREADS) void k_maskset_index(const int32_t *__restrict__ tile_param,
+                                                               const int32_t *__restrict__ tile_begin,
+                                                               const int64_t *__restrict__ numel_tab,
+                                                               const uint8_t *const *__restrict__ masks,
+                                                               int32_t *const *__restrict__ idx_true,
+                                                               int32_t *const *__restrict__ idx_false,
+                                                               const unsigned long long *__restrict__ tile_offsets,
+                                                               int n_tiles) {
+    for (int i = 0; i < MASK_TPB; ++i) {
+        const int gtile = blockIdx.x * MASK_TPB + i;
+        if (gtile >= n_tiles) break;
+        maskset_index_tile(gtile, tile_param, tile_begin, numel_tab, masks, idx_true, idx_false, tile_offsets);
     }
 }
 
@@ -1037,9 +1056,9 @@ extern "C" int svdq_maskset_indices(const svdq_maskset *ms, const void *mask_ptr
     hipLaunchKernelGGL(k_maskset_scan, dim3(ms->n_params), dim3(1024), 0, st, ms->d_tile_begin, ms->d_numel, tile_counts,
                        tile_offsets, reinterpret_cast<long long *>(count_true),
                        reinterpret_cast<long long *>(count_false));
-    hipLaunchKernelGGL(k_maskset_index, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
+    hipLaunchKernelGGL(k_maskset_index, dim3((ms->n_tiles + MASK_TPB - 1) / MASK_TPB), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
                        ms->d_numel, mp, reinterpret_cast<int32_t *const *>(idx_true_ptrs),
-                       reinterpret_cast<int32_t *const *>(idx_false_ptrs), tile_offsets);
+                       reinterpret_cast<int32_t *const *>(idx_false_ptrs), tile_offsets, ms->n_tiles);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
@@ -1072,10 +1091,10 @@ extern "C" int svdq_maskset_combine_indices(const svdq_maskset *ms, const void *
     hipLaunchKernelGGL(k_maskset_scan, dim3(ms->n_params), dim3(1024), 0, st, ms->d_tile_begin, ms->d_numel, tile_counts,
                        tile_offsets, reinterpret_cast<long long *>(count_true),
                        reinterpret_cast<long long *>(count_false));
-    hipLaunchKernelGGL(k_maskset_index, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
+    hipLaunchKernelGGL(k_maskset_index, dim3((ms->n_tiles + MASK_TPB - 1) / MASK_TPB), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
                        ms->d_numel, reinterpret_cast<const uint8_t *const *>(out_ptrs),
                        reinterpret_cast<int32_t *const *>(idx_true_ptrs),
-                       reinterpret_cast<int32_t *const *>(idx_false_ptrs), tile_offsets);
+                       reinterpret_cast<int32_t *const *>(idx_false_ptrs), tile_offsets, ms->n_tiles);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
@@ -1083,7 +1102,7 @@ extern "C" int svdq_maskset_combine_indices(const svdq_maskset *ms, const void *
 // numpy.packbits order (first element = most significant bit), one stream per task.  Combining them from the
 // packed form reads N/8 bytes per element instead of N: parameter q's elements are bits bit_off[q] + e of every
 // stream.  Output: the combined mask as bool bytes (what the reference hands on), tile counts for the index build.
-__global__ __launch_bounds__(ELT_THREADS) void k_maskset_combine_packed(const int32_t *__restrict__ tile_param,
+__device__ void maskset_combine_packed_tile(int gtile, const int32_t *__restrict__ tile_param,
                                                                         const int32_t *__restrict__ tile_begin,
                                                                         const int64_t *__restrict__ numel_tab,
                                                                         const uint8_t *const *__restrict__ streams,
@@ -1095,9 +1114,9 @@ __global__ __launch_bounds__(ELT_THREADS) void k_maskset_combine_packed(const in
     // the tile's packed bytes of every stream are fetched with 16-byte loads into LDS first (17 chunks cover the 257
     // bytes a 2048-element tile can touch at an arbitrary bit offset); byte loads per thread would waste the bus
     __shared__ __attribute__((aligned(16))) uint8_t S[SVDQ_MAX_TASKS][17 * 16];
-    const int q = tile_param[blockIdx.x];
+    const int q = tile_param[gtile];
     const int64_t numel = numel_tab[q];
-    const int64_t tile0 = (int64_t)(blockIdx.x - tile_begin[q]) * MASK_TILE;
+    const int64_t tile0 = (int64_t)(gtile - tile_begin[q]) * MASK_TILE;
     const int64_t base = tile0 + (int64_t)threadIdx.x * 8;
     const int64_t c0 = ((bit_off[q] + tile0) >> 3) & ~(int64_t)15;   // first 16-byte chunk of this tile in every stream
     for (int i = threadIdx.x; i < n_masks * 17; i += ELT_THREADS) {
@@ -1156,7 +1175,25 @@ __global__ __launch_bounds__(ELT_THREADS) void k_maskset_combine_packed(const in
         cnt = (unsigned)__popcll(res);
     }
     const unsigned tot = block_sum_u32(cnt);
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+    if (threadIdx.x == 0) tile_counts[gtile] = tot;
+    __syncthreads();   // the LDS image is reused by the block's next tile
+}
+
+__global__ __launch_bounds__(ELT_THREADS) void k_maskset_combine_packed(const int32_t *__restrict__ tile_param,
+                                                                        const int32_t *__restrict__ tile_begin,
+                                                                        const int64_t *__restrict__ numel_tab,
+                                                                        const uint8_t *const *__restrict__ streams,
+                                                                        const int64_t *__restrict__ bit_off,
+                                                                        const int64_t *__restrict__ stream_bytes,
+                                                                        int n_masks, int strategy,
+                                                                        uint8_t *const *__restrict__ outs,
+                                                                        unsigned *__restrict__ tile_counts, int n_tiles) {
+    for (int i = 0; i < MASK_TPB; ++i) {
+        const int gtile = blockIdx.x * MASK_TPB + i;
+        if (gtile >= n_tiles) break;
+        maskset_combine_packed_tile(gtile, tile_param, tile_begin, numel_tab, streams, bit_off, stream_bytes, n_masks,
+                                    strategy, outs, tile_counts);
+    }
 }
 
 extern "C" int svdq_maskset_combine_packed_indices(const svdq_maskset *ms, const void *stream_ptrs,
@@ -1188,16 +1225,16 @@ extern "C" int svdq_maskset_combine_packed_indices(const svdq_maskset *ms, const
     unsigned *tile_counts = reinterpret_cast<unsigned *>(wb);
     unsigned long long *tile_offsets =
         reinterpret_cast<unsigned long long *>(wb + svdq_align_up((int64_t)ms->n_tiles * 4, 256));
-    hipLaunchKernelGGL(k_maskset_combine_packed, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param,
+    hipLaunchKernelGGL(k_maskset_combine_packed, dim3((ms->n_tiles + MASK_TPB - 1) / MASK_TPB), dim3(ELT_THREADS), 0, st, ms->d_tile_param,
                        ms->d_tile_begin, ms->d_numel, reinterpret_cast<const uint8_t *const *>(stream_ptrs), bit_offsets,
-                       stream_bytes, n_masks, strategy, reinterpret_cast<uint8_t *const *>(out_ptrs), tile_counts);
+                       stream_bytes, n_masks, strategy, reinterpret_cast<uint8_t *const *>(out_ptrs), tile_counts, ms->n_tiles);
     hipLaunchKernelGGL(k_maskset_scan, dim3(ms->n_params), dim3(1024), 0, st, ms->d_tile_begin, ms->d_numel, tile_counts,
                        tile_offsets, reinterpret_cast<long long *>(count_true),
                        reinterpret_cast<long long *>(count_false));
-    hipLaunchKernelGGL(k_maskset_index, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
+    hipLaunchKernelGGL(k_maskset_index, dim3((ms->n_tiles + MASK_TPB - 1) / MASK_TPB), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
                        ms->d_numel, reinterpret_cast<const uint8_t *const *>(out_ptrs),
                        reinterpret_cast<int32_t *const *>(idx_true_ptrs),
-                       reinterpret_cast<int32_t *const *>(idx_false_ptrs), tile_offsets);
+                       reinterpret_cast<int32_t *const *>(idx_false_ptrs), tile_offsets, ms->n_tiles);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
