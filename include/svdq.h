@@ -50,12 +50,9 @@ typedef struct svdq_config {
     int32_t low_bits;          /* svd_low_bits 1..8                                  */
     int32_t rtvq_stages;       /* svd_rtvq_stages 1..SVDQ_MAX_STAGES                 */
     int32_t unit_rows;         /* 0 = auto; rows per work unit (multiple of 256)     */
-    int32_t reserved;          /* schedule bits of svdq_compress, 0 = four whole-batch launches.
-                                  bit 2: fused persistent schedule (one launch for gram + eig + basis_project with
-                                         in-memory ready flags; bits 8..23 = lag in MB between the two passes of a
-                                         parameter, 0 = default);
-                                  else bits 8..23: group size in MB of the multi-stream pipeline, bits 4..7 its lag;
-                                  bit 0: reverse unit order in pass 2.  Results are bit-identical in every mode. */
+    int32_t reserved;          /* measurement switches, 0 in production.  bit 0: reverse unit order in pass 2;
+                                  bit 1: fp32-product Gram for every N (the round-1 kernel; sigma then only resolves
+                                  down to ~3e-4 sigma_0 and smaller ones are treated as null directions). */
 } svdq_config;
 
 /* Byte sizes / strides the caller needs to allocate outputs (all device memory). */

@@ -139,6 +139,8 @@ extern "C" int svdq_plan_create(svdq_plan **out, int32_t n_tasks, int32_t n_para
     off += svdq_align_up((int64_t)n_params * SVDQ_RC * nn * 8, 256);  // level-2 partials (k_reduce)
     pl->ws_cpart2_off = off;
     off += svdq_align_up((int64_t)n_params * SVDQ_RC * nn * 8, 256);
+    pl->ws_flag_off = off;
+    off += svdq_align_up((int64_t)n_params * 4, 256);                 // N > 16: parameters that need the fp64 Gram pass
     pl->sizes.workspace_bytes = off;
     pl->sizes.basis_bytes = basis_bytes;
     pl->sizes.mean_floats = mean_floats;
@@ -164,94 +166,6 @@ extern "C" int svdq_plan_create(svdq_plan **out, int32_t n_tasks, int32_t n_para
     L.total_bytes = off;
     pl->sizes.small_bytes = off;
 
-    // fused persistent schedule: the item queue.  Gram items in parameter order; the projection items of a
-    // parameter become eligible once `lag` bytes of Gram work have been queued after the parameter's last Gram
-    // item (time for its eigen-stage), and are then interleaved one (two when many wait) per Gram item.
-    pl->fused = (cfg->reserved >> 2) & 1;
-    if (pl->fused) {
-        int64_t lag = (int64_t)((cfg->reserved >> 8) & 0xffff) * 1000000;
-        if (lag <= 0) lag = 192 * 1000000LL;
-        pl->n_items = 2 * pl->n_units;
-        int32_t *items = (int32_t *)malloc(sizeof(int32_t) * (size_t)pl->n_items);
-        int32_t *bq = (int32_t *)malloc(sizeof(int32_t) * (size_t)pl->n_units);   // FIFO of eligible projection units
-        int64_t *done_pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_params);
-        int64_t pos = 0;
-        int n = 0, bq_head = 0, bq_tail = 0, next_pending = 0;  // parameters [next_pending, p) wait for their lag
-        for (int p = 0; p < n_params; ++p) {
-            const SvdqParam &pd = pl->h_params[p];
-            for (int32_t i = 0; i < pd.unit_count; ++i) {
-                const int32_t u = pd.unit_begin + i;
-                items[n++] = u;
-                pos += (int64_t)pl->h_units[u].nrows * N * 4;
-                while (next_pending < p && pos - done_pos[next_pending] >= lag) {
-                    const SvdqParam &q = pl->h_params[next_pending++];
-                    for (int32_t j = 0; j < q.unit_count; ++j) bq[bq_tail++] = q.unit_begin + j;
-                }
-                if (bq_head < bq_tail) items[n++] = (int32_t)(0x80000000u | (uint32_t)bq[bq_head++]);
-                if (bq_tail - bq_head > 256) items[n++] = (int32_t)(0x80000000u | (uint32_t)bq[bq_head++]);
-            }
-            done_pos[p] = pos;
-        }
-        while (next_pending < n_params) {
-            const SvdqParam &q = pl->h_params[next_pending++];
-            for (int32_t j = 0; j < q.unit_count; ++j) bq[bq_tail++] = q.unit_begin + j;
-        }
-        while (bq_head < bq_tail) items[n++] = (int32_t)(0x80000000u | (uint32_t)bq[bq_head++]);
-        free(bq);
-        free(done_pos);
-        pl->ctl_bytes = (int64_t)sizeof(int32_t) * (4 + (int64_t)n_params * (SVDQ_RC + 2));
-        hipError_t fe = (n == pl->n_items) ? hipSuccess : hipErrorUnknown;
-        if (fe == hipSuccess) fe = hipMalloc((void **)&pl->d_items, sizeof(int32_t) * (size_t)pl->n_items);
-        if (fe == hipSuccess) fe = hipMalloc((void **)&pl->d_ctl, (size_t)pl->ctl_bytes);
-        if (fe == hipSuccess)
-            fe = hipMemcpy(pl->d_items, items, sizeof(int32_t) * (size_t)pl->n_items, hipMemcpyHostToDevice);
-        free(items);
-        if (fe != hipSuccess) {
-            svdq_set_error("fused schedule setup failed: %s", hipGetErrorString(fe));
-            svdq_plan_destroy(pl);
-            return SVDQ_EHIP;
-        }
-    }
-
-    // cache-resident pipeline: groups of consecutive parameters with >= group_mb MB of input
-    const int group_mb = pl->fused ? 0 : (cfg->reserved >> 8) & 0xffff;
-    pl->lag = (cfg->reserved >> 4) & 0xf;
-    if (pl->lag < 1) pl->lag = 2;
-    if (group_mb > 0) {
-        pl->grp_p0 = (int32_t *)calloc(n_params, sizeof(int32_t));
-        pl->grp_n = (int32_t *)calloc(n_params, sizeof(int32_t));
-        int p0 = 0;
-        double acc = 0.0;
-        for (int p = 0; p < n_params; ++p) {
-            acc += (double)rows[p] * N * 4.0 / 1e6;
-            if (acc >= group_mb || p == n_params - 1) {
-                pl->grp_p0[pl->n_groups] = p0;
-                pl->grp_n[pl->n_groups] = p + 1 - p0;
-                ++pl->n_groups;
-                p0 = p + 1;
-                acc = 0.0;
-            }
-        }
-        pl->ev_gram = (hipEvent_t *)calloc(pl->n_groups, sizeof(hipEvent_t));
-        pl->ev_eig = (hipEvent_t *)calloc(pl->n_groups, sizeof(hipEvent_t));
-        pl->ev_bp = (hipEvent_t *)calloc(pl->n_groups, sizeof(hipEvent_t));
-        hipError_t ee = hipSuccess;
-        for (int i = 0; i < SVDQ_NSIDE && ee == hipSuccess; ++i)
-            ee = hipStreamCreateWithFlags(&pl->side[i], hipStreamNonBlocking);
-        for (int g = 0; g < pl->n_groups && ee == hipSuccess; ++g) {
-            ee = hipEventCreateWithFlags(&pl->ev_gram[g], hipEventDisableTiming);
-            if (ee == hipSuccess) ee = hipEventCreateWithFlags(&pl->ev_eig[g], hipEventDisableTiming);
-            if (ee == hipSuccess) ee = hipEventCreateWithFlags(&pl->ev_bp[g], hipEventDisableTiming);
-        }
-        if (ee == hipSuccess) ee = hipEventCreateWithFlags(&pl->ev_start, hipEventDisableTiming);
-        if (ee == hipSuccess) ee = hipStreamCreateWithFlags(&pl->gram_stream, hipStreamNonBlocking);
-        if (ee != hipSuccess) {
-            svdq_set_error("pipeline stream/event creation failed: %s", hipGetErrorString(ee));
-            svdq_plan_destroy(pl);
-            return SVDQ_EHIP;
-        }
-    }
-
     hipError_t e = hipMalloc((void **)&pl->d_params, sizeof(SvdqParam) * n_params);
     if (e == hipSuccess) e = hipMalloc((void **)&pl->d_units, sizeof(SvdqUnit) * n_units);
     if (e == hipSuccess)
@@ -271,22 +185,6 @@ extern "C" void svdq_plan_destroy(svdq_plan *pl) {
     if (pl->d_params) (void)hipFree(pl->d_params);
     if (pl->d_units) (void)hipFree(pl->d_units);
     if (pl->d_bits) (void)hipFree(pl->d_bits);
-    if (pl->d_items) (void)hipFree(pl->d_items);
-    if (pl->d_ctl) (void)hipFree(pl->d_ctl);
-    for (int g = 0; g < pl->n_groups; ++g) {
-        if (pl->ev_gram && pl->ev_gram[g]) (void)hipEventDestroy(pl->ev_gram[g]);
-        if (pl->ev_eig && pl->ev_eig[g]) (void)hipEventDestroy(pl->ev_eig[g]);
-        if (pl->ev_bp && pl->ev_bp[g]) (void)hipEventDestroy(pl->ev_bp[g]);
-    }
-    if (pl->ev_start) (void)hipEventDestroy(pl->ev_start);
-    if (pl->gram_stream) (void)hipStreamDestroy(pl->gram_stream);
-    free(pl->ev_bp);
-    for (int i = 0; i < SVDQ_NSIDE; ++i)
-        if (pl->side[i]) (void)hipStreamDestroy(pl->side[i]);
-    free(pl->grp_p0);
-    free(pl->grp_n);
-    free(pl->ev_gram);
-    free(pl->ev_eig);
     free(pl->h_params);
     free(pl->h_units);
     free(pl);
@@ -355,8 +253,11 @@ static int gram_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows
     if (int rc = check_range(pl, param0, nparams)) return rc;
     int u0, nu;
     unit_range(pl, param0, nparams, &u0, &nu);
+    // N <= 16: exact products on the fp64 MFMA (pass 1 stays HBM-bound); N > 16: fp32 products first, the fp64 pass only
+    // for the parameters the eigen-stage flags (eig_range).  cfg.reserved bit 1 keeps fp32 products throughout (A/B).
+    const int f64 = (pl->ntp <= 16 && !(pl->cfg.reserved & 2)) ? 1 : 0;
     return svdq_launch_gram(pl, ptrs, rows_dev, reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off)), u0, nu,
-                            pl->cfg.center, idx, base, (hipStream_t)stream);
+                            pl->cfg.center, idx, base, f64, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int svdq_gram_center_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
@@ -373,8 +274,10 @@ extern "C" int svdq_task_gram(const svdq_plan *pl, const void *ptrs, const int64
     hipStream_t st = (hipStream_t)stream;
     double *part = reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off));
     double *part2 = reinterpret_cast<double *>(ws(workspace, pl->ws_gram2_off));
-    if (int rc = svdq_launch_gram(pl, ptrs, rows_dev, part, 0, pl->n_units, /*center=*/0, nullptr, nullptr, st)) return rc;
-    if (int rc = svdq_launch_reduce(pl, part, part2, 0, pl->n_params, st)) return rc;
+    if (int rc = svdq_launch_gram(pl, ptrs, rows_dev, part, 0, pl->n_units, /*center=*/0, nullptr, nullptr,
+                                  pl->ntp <= 16, nullptr, st))
+        return rc;
+    if (int rc = svdq_launch_reduce(pl, part, part2, 0, pl->n_params, nullptr, st)) return rc;
     return svdq_launch_gram_total(pl, part2, out_gram, st);
 }
 
@@ -385,14 +288,26 @@ static int eig_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
         return SVDQ_EINVAL;
     }
     if (int rc = check_range(pl, param0, nparams)) return rc;
-    if (int rc = svdq_launch_reduce(pl, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram_off)),
-                                    reinterpret_cast<double *>(ws(workspace, pl->ws_gram2_off)), param0, nparams,
-                                    (hipStream_t)stream))
+    hipStream_t st = (hipStream_t)stream;
+    double *part = reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off));
+    double *part2 = reinterpret_cast<double *>(ws(workspace, pl->ws_gram2_off));
+    float *W = reinterpret_cast<float *>(ws(workspace, pl->ws_w_off));
+    double *c0 = reinterpret_cast<double *>(ws(workspace, pl->ws_c0_off));
+    uint8_t *sm = reinterpret_cast<uint8_t *>(small);
+    const bool refine = pl->ntp > 16 && !(pl->cfg.reserved & 2);
+    int32_t *flags = refine ? reinterpret_cast<int32_t *>(ws(workspace, pl->ws_flag_off)) : nullptr;
+    if (int rc = svdq_launch_reduce(pl, part, part2, param0, nparams, nullptr, st)) return rc;
+    if (int rc = svdq_launch_eig(pl, ptrs, rows_dev, part2, W, c0, sm, param0, nparams, idx, base, nullptr, flags, st))
         return rc;
-    return svdq_launch_eig(pl, ptrs, rows_dev, reinterpret_cast<const double *>(ws(workspace, pl->ws_gram2_off)),
-                           reinterpret_cast<float *>(ws(workspace, pl->ws_w_off)),
-                           reinterpret_cast<double *>(ws(workspace, pl->ws_c0_off)), reinterpret_cast<uint8_t *>(small),
-                           param0, nparams, idx, base, (hipStream_t)stream);
+    if (!refine) return SVDQ_OK;
+    // N > 16: the parameters whose spectrum reaches into the band fp32-product sums do not resolve are accumulated
+    // again with exact products (v_mfma_f64_16x16x4_f64) and solved again; units of all other parameters return at
+    // once, so a batch without such a parameter pays three near-empty launches
+    int u0, nu;
+    unit_range(pl, param0, nparams, &u0, &nu);
+    if (int rc = svdq_launch_gram(pl, ptrs, rows_dev, part, u0, nu, pl->cfg.center, idx, base, 1, flags, st)) return rc;
+    if (int rc = svdq_launch_reduce(pl, part, part2, param0, nparams, flags, st)) return rc;
+    return svdq_launch_eig(pl, ptrs, rows_dev, part2, W, c0, sm, param0, nparams, idx, base, flags, nullptr, st);
 }
 
 extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
@@ -439,7 +354,7 @@ extern "C" int svdq_coeff_quantize_range(const svdq_plan *pl, void *workspace, v
     if (int rc = check_range(pl, param0, nparams)) return rc;
     if (int rc = svdq_launch_reduce(pl, reinterpret_cast<const double *>(ws(workspace, pl->ws_cpart_off)),
                                     reinterpret_cast<double *>(ws(workspace, pl->ws_cpart2_off)), param0, nparams,
-                                    (hipStream_t)stream))
+                                    nullptr, (hipStream_t)stream))
         return rc;
     return svdq_launch_coeff(pl, reinterpret_cast<const double *>(ws(workspace, pl->ws_cpart2_off)),
                              reinterpret_cast<const double *>(ws(workspace, pl->ws_c0_off)),
@@ -469,70 +384,11 @@ extern "C" int svdq_coeff_quantize(const svdq_plan *pl, void *workspace, void *s
     return svdq_coeff_quantize_range(pl, workspace, small, 0, pl->n_params, stream);
 }
 
-// Cache-resident schedule over groups of consecutive parameters (>= group_mb MB of deltas each):
-//   gram stream   : gram(0) gram(1) ...            gram(g) waits for bp(g - lag)  (back-pressure)
-//   side streams  : eig(g) as soon as gram(g) is done (independent solves, dealt over SVDQ_NSIDE streams)
-//   caller stream : bp(g) as soon as eig(g) is done, finally the coefficient epilogue
-// Two streaming kernels (one gram, one basis_project) are in flight at any time, so the ramp and tail
-// of per-group launches overlap, and basis_project(g) runs while group g's deltas are still (mostly)
-// resident in the 256 MiB Infinity Cache.  Everything is joined back into the caller's stream.
-static int compress_pipelined(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
-                              void *small, void *basis, float *mean, hipStream_t main) {
-    const int G = pl->n_groups;
-    HIP_TRY(hipEventRecord(pl->ev_start, main));
-    HIP_TRY(hipStreamWaitEvent(pl->gram_stream, pl->ev_start, 0));
-    for (int i = 0; i < SVDQ_NSIDE; ++i) HIP_TRY(hipStreamWaitEvent(pl->side[i], pl->ev_start, 0));
-    for (int g = 0; g < G; ++g) {
-        if (g >= pl->lag) HIP_TRY(hipStreamWaitEvent(pl->gram_stream, pl->ev_bp[g - pl->lag], 0));
-        int rc = svdq_gram_center_range(pl, ptrs, rows_dev, workspace, pl->grp_p0[g], pl->grp_n[g], pl->gram_stream);
-        if (rc != SVDQ_OK) return rc;
-        HIP_TRY(hipEventRecord(pl->ev_gram[g], pl->gram_stream));
-        hipStream_t sd = pl->side[g % SVDQ_NSIDE];
-        HIP_TRY(hipStreamWaitEvent(sd, pl->ev_gram[g], 0));
-        rc = svdq_eig_rank_select_range(pl, ptrs, rows_dev, workspace, small, pl->grp_p0[g], pl->grp_n[g], sd);
-        if (rc != SVDQ_OK) return rc;
-        HIP_TRY(hipEventRecord(pl->ev_eig[g], sd));
-        HIP_TRY(hipStreamWaitEvent(main, pl->ev_eig[g], 0));
-        rc = svdq_basis_project_range(pl, ptrs, rows_dev, workspace, small, basis, mean, pl->grp_p0[g], pl->grp_n[g],
-                                      main);
-        if (rc != SVDQ_OK) return rc;
-        HIP_TRY(hipEventRecord(pl->ev_bp[g], main));
-    }
-    return svdq_coeff_quantize(pl, workspace, small, main);
-}
-
-// One persistent launch for gram + eig + basis_project (k_fused), then the coefficient epilogue.
-static int compress_fused(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, void *small,
-                          void *basis, float *mean, hipStream_t st) {
-    if (!ptrs || !workspace || !small || !basis) {
-        svdq_set_error("null argument");
-        return SVDQ_EINVAL;
-    }
-    if ((reinterpret_cast<uintptr_t>(basis) & 255) != 0) {
-        svdq_set_error("basis buffer must be 256-byte aligned");
-        return SVDQ_EINVAL;
-    }
-    uint8_t *sm = reinterpret_cast<uint8_t *>(small);
-    HIP_TRY(hipMemsetAsync(pl->d_ctl, 0, (size_t)pl->ctl_bytes, st));
-    int rc = svdq_launch_fused(pl, ptrs, rows_dev, reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off)),
-                               reinterpret_cast<double *>(ws(workspace, pl->ws_gram2_off)),
-                               reinterpret_cast<float *>(ws(workspace, pl->ws_w_off)),
-                               reinterpret_cast<double *>(ws(workspace, pl->ws_c0_off)), sm,
-                               reinterpret_cast<uint8_t *>(basis), mean,
-                               reinterpret_cast<double *>(ws(workspace, pl->ws_cpart_off)), st);
-    if (rc != SVDQ_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(sm + pl->small.status_off, pl->d_ctl + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    return svdq_coeff_quantize(pl, workspace, small, st);
-}
-
 extern "C" int svdq_compress(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
                              void *small, void *basis, float *mean, void *stream) {
-    if (pl && pl->fused) return compress_fused(pl, ptrs, rows_dev, workspace, small, basis, mean, (hipStream_t)stream);
     if (pl && small)
         HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(small) + pl->small.status_off, 0, sizeof(int32_t),
                                (hipStream_t)stream));
-    if (pl && pl->n_groups > 1)
-        return compress_pipelined(pl, ptrs, rows_dev, workspace, small, basis, mean, (hipStream_t)stream);
     int rc = svdq_gram_center(pl, ptrs, rows_dev, workspace, stream);
     if (rc == SVDQ_OK) rc = svdq_eig_rank_select(pl, ptrs, rows_dev, workspace, small, stream);
     if (rc == SVDQ_OK) rc = svdq_basis_project(pl, ptrs, rows_dev, workspace, small, basis, mean, stream);

@@ -15,7 +15,6 @@
 #include "../../include/svdq.h"
 
 #define SVDQ_BLK_ROWS 256
-#define SVDQ_NSIDE 4  // side streams the per-group eigen-solves are dealt over
 #define SVDQ_RC 16  // level-2 partial chunks per parameter (k_reduce)
 #ifndef SVDQ_XS
 #define SVDQ_XS 260  // LDS row stride (floats) of one task's 256-row strip: 256 + pad, multiple of 4 (16-B alignment)
@@ -43,25 +42,14 @@ struct svdq_plan {
     svdq_sizes sizes;
     svdq_small_layout small;
     // workspace offsets (bytes)
-    int64_t ws_gram_off, ws_cpart_off, ws_w_off, ws_c0_off, ws_gram2_off, ws_cpart2_off;
+    int64_t ws_gram_off, ws_cpart_off, ws_w_off, ws_c0_off, ws_gram2_off, ws_cpart2_off, ws_flag_off;
     // host copies
     SvdqParam *h_params;
     SvdqUnit *h_units;
     // device tables
     SvdqParam *d_params;
     SvdqUnit *d_units;
-    // optional cache-resident pipeline (cfg.reserved bits 8..23 = group size in MB, bits 4..7 = lag)
-    int32_t n_groups, lag;
-    int32_t *grp_p0, *grp_n;
-    hipEvent_t *ev_gram, *ev_eig, *ev_bp, ev_start;
-    hipStream_t gram_stream;
-    hipStream_t side[SVDQ_NSIDE];
-    // optional fused persistent schedule (cfg.reserved bit 2; bits 8..23 = lag in MB between the Gram and the
-    // projection of a parameter): item queue and the zero-initialised control block
     int32_t *d_bits;  // optional per-parameter low_bits (svdq_plan_set_low_bits), NULL = cfg.low_bits everywhere
-    int32_t fused, n_items;
-    int32_t *d_items, *d_ctl;
-    int64_t ctl_bytes;
 };
 
 __host__ __device__ static inline int64_t svdq_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -73,21 +61,22 @@ void svdq_set_error(const char *fmt, ...);
 
 // launchers (defined in the .hip files)
 // idx: NULL, or a device table [n_params] of int32 index lists (gather mode, see svdq_compress_gather);
-// base: NULL, or a device table [n_params] of base tensors (minus-base mode, see svdq_compress_from_base)
+// base: NULL, or a device table [n_params] of base tensors (minus-base mode, see svdq_compress_from_base);
+// only: NULL, or a device table [n_params] of int32 -- parameters whose entry is 0 are skipped (refinement pass)
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                     int unit0, int nunits, int center, const void *idx, const void *base, hipStream_t st);
+                     int unit0, int nunits, int center, const void *idx, const void *base, int f64,
+                     const int32_t *only, hipStream_t st);
 int svdq_launch_gram_total(const svdq_plan *pl, const double *part2, double *out, hipStream_t st);
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
                               double *cpart, int unit0, int nunits, int reverse, const void *idx, const void *base,
                               hipStream_t st);
-int svdq_launch_fused(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                      double *gram_part2, float *W, double *c0, uint8_t *small, uint8_t *basis, float *mean,
-                      double *cpart, hipStream_t st);
+// refine_out: NULL, or a device table [n_params] that receives 1 where a singular value lies in the band the fp32-product
+// Gram does not resolve (then the caller re-accumulates those parameters in fp64 and calls again with only = that table)
 int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W,
                     double *c0, uint8_t *small, int param0, int nparams, const void *idx, const void *base,
-                    hipStream_t st);
+                    const int32_t *only, int32_t *refine_out, hipStream_t st);
 int svdq_launch_reduce(const svdq_plan *pl, const double *part, double *part2, int param0, int nparams,
-                       hipStream_t st);
+                       const int32_t *only, hipStream_t st);
 int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, const double *c0, uint8_t *small, int param0,
                       int nparams, hipStream_t st);

@@ -80,7 +80,8 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
                           double *__restrict__ c0_out, float *__restrict__ sigma_out, int32_t *__restrict__ k_out,
                           int32_t *__restrict__ r_out, float *__restrict__ energy_out,
                           int64_t *__restrict__ rows_out, const int32_t *const *__restrict__ idx_ptrs = nullptr,
-                          const float *const *__restrict__ base_ptrs = nullptr) {
+                          const float *const *__restrict__ base_ptrs = nullptr,
+                          int32_t *__restrict__ refine_out = nullptr, double resolve = 1e-6) {
 #pragma clang fp contract(off)
     constexpr int LDX = NMAX + 1;      // padded leading dimension
     double *Gd = lds;                  // [NMAX*NMAX] (deflated) Gram, kept for the completion column
@@ -103,8 +104,8 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
     }
     phase_sync<THREADS>();
 
-    // Centred rows sum to zero, so 1/sqrt(N) is an exact null vector of Tc.  The fp32-product Gram only
-    // resolves sigma down to ~1e-4 sigma_0, so deflate that direction explicitly in fp64:
+    // Centred rows sum to zero, so 1/sqrt(N) is an exact null vector of Tc.  Deflate that direction explicitly in fp64
+    // (the fp32 rounding of the centred rows leaves ~1e-7 sigma_0 of it in the data):
     // G <- C G C, C = I - 11^T/N.  (LAPACK reports ~1e-7 sigma_0 noise there; we report ~0.)
     if (center) {
         if (tid < n) {
@@ -273,22 +274,30 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
         r_out[p] = r;
         energy_out[p] = (kk > 0 && r > 0) ? cum[kk - 1] : 0.f;
         rows_out[p] = D;
-        // first direction below the fp32 resolution of the data, if any
+        // first direction below the resolution of this Gram (exact products: the fp32 resolution of the data), if any
         int i0 = -1;
         if (sig[0] > 0.0 && D > 0)
             for (int i = 0; i < r; ++i)
-                if (!(sig[i] > 1e-6 * sig[0])) {
+                if (!(sig[i] > resolve * sig[0])) {
                     i0 = i;
                     break;
                 }
         s_i0 = i0;
+        // N > 16 accumulates fp32 products first: a sigma between the noise floor of the explicitly deflated null
+        // direction (~1e-8 sigma_0) and 2e-2 sigma_0 may be off by more than rtol 2e-5 -> ask for the fp64 pass
+        if (refine_out) {
+            int need = 0;
+            for (int i = 1; i < r; ++i)
+                if (sig[i] > 3e-7 * sig[0] && sig[i] < 2e-2 * sig[0]) need = 1;
+            refine_out[p] = need;
+        }
     }
     // W[t][i] = sgn_i V[t][order[i]] / sigma_i for the resolved directions, 0 otherwise (A is free now)
     const double s0 = sig[0];
     for (int e = tid; e < nn; e += THREADS) {
         const int t = e / n, i = e % n;
         double wv = 0.0;
-        if (i < r && sig[i] > 1e-6 * s0 && sig[i] > 0.0) wv = sgn[i] * V[t * LDX + order[i]] / sig[i];
+        if (i < r && sig[i] > resolve * s0 && sig[i] > 0.0) wv = sgn[i] * V[t * LDX + order[i]] / sig[i];
         A[t * LDX + i] = wv;
     }
     // row 0 of every task (gather mode: the first selected element of the tensor)
@@ -352,7 +361,7 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
             if (have_col && i == i0) {
                 for (int t2 = 0; t2 < n; ++t2) cv += A[t2 * LDX + i] * Gd[t2 * n + t];
                 cv += spike * xc0[t];
-            } else if (sig[i] > 1e-6 * s0 && sig[i] > 0.0) {
+            } else if (sig[i] > resolve * s0 && sig[i] > 0.0) {
                 cv = sig[i] * sgn[i] * V[t * LDX + order[i]];
             }
         }

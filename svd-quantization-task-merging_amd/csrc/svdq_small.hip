@@ -42,8 +42,9 @@ __device__ void reduce_partials(const double *__restrict__ part, int s0, int s1,
 // partials per parameter.  Keeps the whole reduction deterministic and off one CU.
 __global__ __launch_bounds__(64) void k_reduce(const SvdqParam *__restrict__ params, int NT, int pack,
                                                const double *__restrict__ part, double *__restrict__ part2,
-                                               int param0) {
+                                               int param0, const int32_t *__restrict__ only) {
     const int p = param0 + blockIdx.x, c = blockIdx.y, nn = NT * NT;
+    if (only && !only[p]) return;
     const SvdqParam pd = params[p];
     const int per = (pd.unit_count + SVDQ_RC - 1) / SVDQ_RC;  // units per chunk
     int ua = c * per, ub = ua + per;
@@ -54,9 +55,9 @@ __global__ __launch_bounds__(64) void k_reduce(const SvdqParam *__restrict__ par
 }
 
 int svdq_launch_reduce(const svdq_plan *pl, const double *part, double *part2, int param0, int nparams,
-                       hipStream_t st) {
+                       const int32_t *only, hipStream_t st) {
     hipLaunchKernelGGL(k_reduce, dim3(nparams, SVDQ_RC), dim3(64), 0, st, pl->d_params, pl->n_tasks, pl->pack,
-                       part, part2, param0);
+                       part, part2, param0, only);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
@@ -98,12 +99,15 @@ __global__ __launch_bounds__(THREADS) void k_eig(const SvdqParam *__restrict__ p
                                                  int32_t *__restrict__ r_out, float *__restrict__ energy_out,
                                                  int64_t *__restrict__ rows_out,
                                                  const int32_t *const *__restrict__ idx_ptrs,
-                                                 const float *const *__restrict__ base_ptrs) {
+                                                 const float *const *__restrict__ base_ptrs,
+                                                 const int32_t *__restrict__ only, int32_t *__restrict__ refine_out,
+                                                 float resolve) {
     __shared__ __attribute__((aligned(16))) double lds[SVDQ_EIG_LDS_BYTES(NMAX) / 8 + 1];
     const int p = param0 + blockIdx.x;
+    if (only && !only[p]) return;
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
     eig_param<THREADS, NMAX>(lds, p, threadIdx.x, D, ptrs, NT, center, thr, max_rank, gram_part2, Wtab, c0_out, sigma_out,
-                             k_out, r_out, energy_out, rows_out, idx_ptrs, base_ptrs);
+                             k_out, r_out, energy_out, rows_out, idx_ptrs, base_ptrs, refine_out, (double)resolve);
 }
 
 // ------------------------------------------------------------------------------------ epilogue
@@ -192,7 +196,11 @@ __global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restri
 // ------------------------------------------------------------------------------------ launchers
 int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part2, float *W,
                     double *c0, uint8_t *small, int param0, int nparams, const void *idx, const void *base,
-                    hipStream_t st) {
+                    const int32_t *only, int32_t *refine_out, hipStream_t st) {
+    // smallest sigma / sigma_0 the Gram behind gram_part2 resolves: exact-product (fp64 MFMA) sums reach the fp32
+    // resolution of the data; fp32-product sums (cfg.reserved bit 1, and N > 16 before its refinement) do not
+    const bool exact = (pl->ntp <= 16 && !(pl->cfg.reserved & 2)) || only != nullptr;
+    const float resolve = exact ? 1e-6f : 3e-4f;
     auto ip = reinterpret_cast<const int32_t *const *>(idx);
     auto bpp = reinterpret_cast<const float *const *>(base);
     const svdq_small_layout &L = pl->small;
@@ -204,11 +212,11 @@ int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_d
     if (pl->n_tasks <= 8)
         hipLaunchKernelGGL((k_eig<64, 8>), dim3(nparams), dim3(64), 0, st, pl->d_params, pp, rows_dev, pl->n_tasks,
                            pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part2, W, c0, param0, sg,
-                           kk, rr, en, ro, ip, bpp);
+                           kk, rr, en, ro, ip, bpp, only, refine_out, resolve);
     else
         hipLaunchKernelGGL((k_eig<256, 32>), dim3(nparams), dim3(256), 0, st, pl->d_params, pp, rows_dev, pl->n_tasks,
                            pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part2, W, c0, param0, sg,
-                           kk, rr, en, ro, ip, bpp);
+                           kk, rr, en, ro, ip, bpp, only, refine_out, resolve);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 

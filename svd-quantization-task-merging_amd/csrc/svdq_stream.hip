@@ -26,7 +26,6 @@
 // Accumulation: fp32 inside a block (64 MFMA k-steps), fp64 across blocks and units.
 
 #include "svdq_common.h"
-#include "svdq_eig.h"
 #include <hip/hip_fp16.h>
 
 #define XS SVDQ_XS
@@ -65,6 +64,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64: operands as the f32 form (one value per lane: A[l&15][l>>4], B[l>>4][l&15]); the
+// accumulator layout differs: lane l holds D[(l>>4) + 4*reg][l&15].  A product of two fp32 values is exact in
+// fp64, so a Gram accumulated this way carries only the ~1e-16 rounding of the running sums.
+__device__ __forceinline__ f64x4 mfma4d(double a, double b, f64x4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ f32x4 zero4() {
@@ -226,13 +234,18 @@ __device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int
 // X: NTP*XS floats of wave-private LDS.
 // MODE 0: contiguous task vectors; 1: gather through an index list (aux[p] = int32 list); 2: fine-tuned tensors
 // minus a base tensor (aux[p] = base)
-template <int NTP, int MODE = 0>
+// F64: the products are accumulated by v_mfma_f64_16x16x4_f64 (exact fp32 x fp32 products, fp64 running sums over the
+// whole unit), which resolves singular values down to ~1e-6 sigma_0 like the reference's LAPACK path; the fp32 form
+// (fp32 sums inside a 256-row block) only reaches ~1e-3..1e-4 sigma_0.  Pass 1 is HBM-bound for N <= 16, so the fp64
+// form is the default there; N > 16 would become MFMA-bound and keeps fp32 products.
+template <int NTP, int MODE = 0, bool F64 = false>
 __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *__restrict__ params,
                                           const SvdqUnit *__restrict__ units,
                                           const float *const *__restrict__ ptrs,
                                           const int64_t *__restrict__ rows_dev, int NT, int center,
                                           double *__restrict__ gram_part,
-                                          const void *const *__restrict__ aux = nullptr) {
+                                          const void *const *__restrict__ aux = nullptr,
+                                          const int32_t *__restrict__ only = nullptr) {
     constexpr bool GATHER = (MODE == 1), SUB = (MODE == 2);
     static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
@@ -240,12 +253,13 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     // N = 17..20: the BB block of the 2x2-blocked Gram is only 4 x 4.  A 16x16x4 MFMA per k-step for it wastes 15/16
     // of the matrix pipe, and pass 1 at N = 20 is MFMA-issue-bound (SQ_WAIT_INST_ANY 69 %, MFMA busy 58 %): the ten
     // products of tasks 16..19 are taken on the vector ALU from the registers the centred rows are still in.
-    constexpr bool VBB = (NTP == 20);
+    constexpr bool VBB = (NTP == 20) && !F64;
     constexpr int NACC = (NB == 1) ? 1 : (VBB ? 2 : 3);  // AA | AA, AB, BB
 
     const int lane = threadIdx.x & 63;
     const SvdqUnit ud = units[uidx];
     const int p = ud.param;
+    if (only && !only[p]) return;  // refinement pass (N > 16): only the parameters the eigen-stage flagged
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
     const int64_t r_begin = ud.row0;
     int64_t r_end = r_begin + ud.nrows;
@@ -261,6 +275,14 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) accd[i][e] = 0.0;
+
+#ifndef SVDQ_GRAM64_CHAINS
+#define SVDQ_GRAM64_CHAINS 1
+#endif
+    constexpr int QC = (NB == 1) ? SVDQ_GRAM64_CHAINS : 1;  // F64: independent accumulation chains per block
+    f64x4 accq[NACC * QC];
+#pragma unroll
+    for (int i = 0; i < NACC * QC; ++i) accq[i] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     double bbd[VBB ? 10 : 1];  // per-lane partial products of tasks (16+a, 16+b), a <= b
 #pragma unroll
@@ -334,8 +356,16 @@ UNROLL_N(SVDQ_UNROLL_GRAM)
             for (int j = 0; j < 8; ++j) {
                 f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 32 * j);
                 if (!valid) a = zero4();
+                if constexpr (F64) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[0] = mfma4(a[e], a[e], acc[0]);
+                    for (int e = 0; e < 4; ++e) {
+                        const double ad = (double)a[e];
+                        accq[e % QC] = mfma4d(ad, ad, accq[e % QC]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[0] = mfma4(a[e], a[e], acc[0]);
+                }
             }
         } else {
             const bool v0ok = c < NTP;
@@ -346,7 +376,23 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
             for (int j = 0; j < 16; ++j) {
                 f32x4 a0 = *reinterpret_cast<const f32x4 *>(x0 + 16 * j);
                 if (!v0ok) a0 = zero4();
-                if constexpr (NB == 1) {
+                if constexpr (F64 && NB == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double ad = (double)a0[e];
+                        accq[e % QC] = mfma4d(ad, ad, accq[e % QC]);
+                    }
+                } else if constexpr (F64) {
+                    f32x4 a1 = *reinterpret_cast<const f32x4 *>(x1 + 16 * j);
+                    if (!v1ok) a1 = zero4();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double d0 = (double)a0[e], d1 = (double)a1[e];
+                        accq[0] = mfma4d(d0, d0, accq[0]);
+                        accq[1] = mfma4d(d0, d1, accq[1]);
+                        accq[2] = mfma4d(d1, d1, accq[2]);
+                    }
+                } else if constexpr (NB == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[0] = mfma4(a0[e], a0[e], acc[0]);
                 } else {
@@ -361,10 +407,12 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
                 }
             }
         }
+        if constexpr (!F64) {
 #pragma unroll
-        for (int i = 0; i < NACC; ++i)
+            for (int i = 0; i < NACC; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) accd[i][e] += (double)acc[i][e];
+                for (int e = 0; e < 4; ++e) accd[i][e] += (double)acc[i][e];
+        }
         wave_sync();
     };
 
@@ -374,22 +422,33 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
         if (rb + SVDQ_BLK_ROWS < r_end) do_block(v1, rb + SVDQ_BLK_ROWS);
 #endif
     }
+    if constexpr (F64) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double t = accq[i * QC][e];
+#pragma unroll
+                for (int q = 1; q < QC; ++q) t += accq[i * QC + q][e];
+                accd[i][e] = t;
+            }
+    }
 
-    // One fp64 partial per slot, dense [NT][NT].  Lane (c,g) holds D[4g+e][c].
+    // One fp64 partial per slot, dense [NT][NT].  Lane (c,g) holds D[4g+e][c] (fp32 MFMA) or D[g+4e][c] (fp64 MFMA).
     const int NN = NT * NT;
     if constexpr (PACK == 2) {
         const int rs = c >> 3, n = c & 7;
         double *dst = gram_part + ((size_t)uidx * 2 + rs) * NN;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int m = 4 * g + e;
+            const int m = F64 ? g + 4 * e : 4 * g + e;
             if ((m >> 3) == rs && (m & 7) < NT && n < NT) dst[(m & 7) * NT + n] = accd[0][e];
         }
     } else {
         double *dst = gram_part + (size_t)uidx * NN;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int m = 4 * g + e;
+            const int m = F64 ? g + 4 * e : 4 * g + e;
             if (m < NT && c < NT) dst[m * NT + c] = accd[0][e];
             if constexpr (NB == 2) {
                 if (m < NT && 16 + c < NT) {
@@ -419,15 +478,25 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
     }
 }
 
-template <int NTP, int MODE>
-__global__ __launch_bounds__(64) void k_gram(const SvdqParam *__restrict__ params,
+// second launch bound = waves per SIMD the register allocation must leave room for: the fp64 accumulators would
+// otherwise cost the N <= 8 and the N <= 16 kernels one resident wave each (measured: -9 % bandwidth)
+#ifndef SVDQ_GRAM64_WAVES8
+#define SVDQ_GRAM64_WAVES8 5
+#endif
+#ifndef SVDQ_GRAM64_WAVES16
+#define SVDQ_GRAM64_WAVES16 3
+#endif
+template <int NTP, int MODE, bool F64>
+__global__ __launch_bounds__(64, (F64 && MODE == 0 && NTP <= 16) ? (NTP <= 8 ? SVDQ_GRAM64_WAVES8 : SVDQ_GRAM64_WAVES16) : 1) void k_gram(const SvdqParam *__restrict__ params,
                                              const SvdqUnit *__restrict__ units,
                                              const float *const *__restrict__ ptrs,
                                              const int64_t *__restrict__ rows_dev, int NT, int center,
                                              double *__restrict__ gram_part, int unit0,
-                                             const void *const *__restrict__ aux) {
+                                             const void *const *__restrict__ aux,
+                                             const int32_t *__restrict__ only) {
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
-    gram_unit<NTP, MODE>(X, unit0 + (int)blockIdx.x, params, units, ptrs, rows_dev, NT, center, gram_part, aux);
+    gram_unit<NTP, MODE, F64>(X, unit0 + (int)blockIdx.x, params, units, ptrs, rows_dev, NT, center, gram_part, aux,
+                              only);
 }
 
 // ------------------------------------------------------------------------------------ pass 2
@@ -1031,213 +1100,44 @@ UNROLL_N(SVDQ_UNROLL_BP2)
         }
 }
 
-// ------------------------------------------------------------------------------------ fused schedule
-// One launch for gram -> eig/rank -> basis+projection (svdq_compress with the fused bit): every workgroup
-// (one wavefront) takes ONE item from a host-built queue through an atomic ticket.  The queue
-// lists every unit twice -- as a Gram item, and, a configurable number of bytes later, as a
-// basis-projection item -- so that pass 2 of a tensor runs while the tensor is still (partly) in the
-// 256 MiB Infinity Cache and the small per-parameter stages cost no launches:
-//   Gram item      : gram_unit, then arrive on the unit's chunk counter; the last arriver of a chunk sums
-//                    the chunk (chunk_sum order = k_reduce's) and arrives on the parameter counter; the last
-//                    arriver of a parameter runs eig_param on its own LDS and raises ready[p].
-//   projection item: waits for ready[p] (bounded spin), then bp_unit.
-// A projection item is queued after ALL Gram items of its parameter and items are fetched in queue
-// order, so whoever a waiter depends on is already running and never waits itself: no deadlock,
-// whatever the residency.  All cross-workgroup hand-offs are agent-scope release/acquire.
-#define SVDQ_SPIN_MAX (1 << 16)
-
-struct SvdqFusedArgs {
-    const SvdqParam *params;
-    const SvdqUnit *units;
-    const int32_t *items;  // bit 31: 0 = Gram item, 1 = projection item; low bits: unit index
-    const float *const *ptrs;
-    const int64_t *rows_dev;
-    double *gram_part, *gram_part2;
-    float *Wtab;
-    double *c0;
-    float *sigma;
-    int32_t *k, *r;
-    float *energy;
-    int64_t *rows_out;
-    uint8_t *basis;
-    float *mean;
-    double *cpart;
-    int32_t *ctl;  // [0] queue head, [1] error flag, [4..) chunk counters, parameter counters, ready flags
-    int32_t n_items, n_params, NT, center, pack, max_rank;
-    float thr;
-};
-
-__device__ __forceinline__ int wave_fetch_add(int32_t *ctr, int lane) {
-    int t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return __builtin_amdgcn_readfirstlane(t);
-}
-
-template <int NTP>
-__device__ __forceinline__ void fused_gram(float *X, int uidx, const SvdqFusedArgs &a) {
-    gram_unit<NTP>(X, uidx, a.params, a.units, a.ptrs, a.rows_dev, a.NT, a.center, a.gram_part);
-}
-
-template <int NTP, bool OUT16>
-__device__ __forceinline__ void fused_bp(float *X, typename OutT<OUT16>::type *OUT, int uidx, const SvdqFusedArgs &a) {
-    bp_unit<NTP, OUT16>(X, OUT, uidx, a.params, a.units, a.ptrs, a.rows_dev, a.NT, a.center, a.Wtab, a.k, a.r, a.basis,
-                        a.mean, a.cpart);
-}
-
-template <int NTP>
-__device__ __forceinline__ void fused_eig(float *X, int p, int lane, int64_t D, const SvdqFusedArgs &a) {
-    eig_param<64, NTP>(reinterpret_cast<double *>(X), p, lane, D, a.ptrs, a.NT, a.center, a.thr, a.max_rank,
-                       a.gram_part2, a.Wtab, a.c0, a.sigma, a.k, a.r, a.energy, a.rows_out);
-}
-
-template <int NTP, bool OUT16>
-__global__ __launch_bounds__(64) void k_fused(const SvdqFusedArgs a) {
-    using out_t = typename OutT<OUT16>::type;
-    __shared__ __attribute__((aligned(16))) float X[NTP * XS];
-    __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];
-    static_assert(sizeof(float) * NTP * XS >= SVDQ_EIG_LDS_BYTES(NTP), "eigen-stage scratch must fit in the strip");
-    const int lane = threadIdx.x & 63;
-    int32_t *chunk_arrive = a.ctl + 4;
-    int32_t *param_arrive = chunk_arrive + (size_t)a.n_params * SVDQ_RC;
-    int32_t *ready = param_arrive + a.n_params;
-    const int nn = a.NT * a.NT;
-    {
-        // the ticket, not blockIdx, orders the items: a workgroup that holds ticket i is running, so everything
-        // a waiter depends on (smaller tickets) is running too, whatever order the hardware dispatches in
-        const int it = wave_fetch_add(a.ctl, lane);
-        if (it >= a.n_items) return;
-        const int32_t code = a.items[it];
-        const int uidx = code & 0x7fffffff;
-        const int p = a.units[uidx].param;
-        if (code >= 0) {
-            fused_gram<NTP>(X, uidx, a);
-            const SvdqParam pd = a.params[p];
-            const int per = (pd.unit_count + SVDQ_RC - 1) / SVDQ_RC;
-            const int c = (uidx - pd.unit_begin) / per;
-            const int ua = c * per;
-            const int ub = ua + per < pd.unit_count ? ua + per : pd.unit_count;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this unit's partial(s) are visible ...
-            if (wave_fetch_add(&chunk_arrive[(size_t)p * SVDQ_RC + c], lane) == ub - ua - 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... to the chunk's last arriver
-                const int sa = (pd.unit_begin + ua) * a.pack, sb = (pd.unit_begin + ub) * a.pack;
-                for (int e = lane; e < nn; e += 64)
-                    a.gram_part2[((size_t)p * SVDQ_RC + c) * nn + e] = chunk_sum(a.gram_part, sa, sb, nn, e);
-                const int nc = (pd.unit_count + per - 1) / per;  // non-empty chunks
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (wave_fetch_add(&param_arrive[p], lane) == nc - 1) {
-                    for (int c2 = nc; c2 < SVDQ_RC; ++c2)  // k_reduce writes zeros for empty chunks
-                        for (int e = lane; e < nn; e += 64) a.gram_part2[((size_t)p * SVDQ_RC + c2) * nn + e] = 0.0;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    const int64_t D = a.rows_dev ? a.rows_dev[p] : pd.rows;
-                    wave_sync();
-                    fused_eig<NTP>(X, p, lane, D, a);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // W, k, r, c0 visible before the flag
-                    if (lane == 0) __hip_atomic_store(&ready[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        } else {
-            int ok = 0;
-            for (int spin = 0; spin < SVDQ_SPIN_MAX; ++spin) {
-                int v = 0;
-                if (lane == 0) v = __hip_atomic_load(&ready[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = __builtin_amdgcn_readfirstlane(v);
-                if (ok) break;
-                __builtin_amdgcn_s_sleep(20);
-            }
-            if (!ok) {  // cannot happen with a queue built by svdq_plan_create; never hang the GPU on a bug
-                if (lane == 0) __hip_atomic_store(&a.ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            fused_bp<NTP, OUT16>(X, OUT, uidx, a);
-        }
-    }
-}
-
-template <int NTP>
-static int launch_fused_t(const svdq_plan *pl, const SvdqFusedArgs &args, hipStream_t st) {
-    if (pl->cfg.fp16)
-        hipLaunchKernelGGL((k_fused<NTP, true>), dim3(args.n_items), dim3(64), 0, st, args);
-    else
-        hipLaunchKernelGGL((k_fused<NTP, false>), dim3(args.n_items), dim3(64), 0, st, args);
-    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
-}
-
-int svdq_launch_fused(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                      double *gram_part2, float *W, double *c0, uint8_t *small, uint8_t *basis, float *mean,
-                      double *cpart, hipStream_t st) {
-    const svdq_small_layout &L = pl->small;
-    SvdqFusedArgs a;
-    a.params = pl->d_params;
-    a.units = pl->d_units;
-    a.items = pl->d_items;
-    a.ptrs = reinterpret_cast<const float *const *>(ptrs);
-    a.rows_dev = rows_dev;
-    a.gram_part = gram_part;
-    a.gram_part2 = gram_part2;
-    a.Wtab = W;
-    a.c0 = c0;
-    a.sigma = reinterpret_cast<float *>(small + L.sigma_off);
-    a.k = reinterpret_cast<int32_t *>(small + L.k_off);
-    a.r = reinterpret_cast<int32_t *>(small + L.r_off);
-    a.energy = reinterpret_cast<float *>(small + L.energy_off);
-    a.rows_out = reinterpret_cast<int64_t *>(small + L.rows_off);
-    a.basis = basis;
-    a.mean = mean;
-    a.cpart = cpart;
-    a.ctl = pl->d_ctl;
-    a.n_items = pl->n_items;
-    a.n_params = pl->n_params;
-    a.NT = pl->n_tasks;
-    a.center = pl->cfg.center;
-    a.pack = pl->pack;
-    a.max_rank = pl->cfg.max_rank;
-    a.thr = pl->cfg.energy_threshold;
-    switch (pl->ntp) {
-        case 4: return launch_fused_t<4>(pl, a, st);
-        case 8: return launch_fused_t<8>(pl, a, st);
-        case 12: return launch_fused_t<12>(pl, a, st);
-        case 16: return launch_fused_t<16>(pl, a, st);
-        case 20: case 24: case 28: case 32:
-            svdq_set_error("the fused schedule is implemented for N <= 16 tasks");
-            return SVDQ_EUNSUPPORTED;
-    }
-    svdq_set_error("unsupported padded task count %d", pl->ntp);
-    return SVDQ_EUNSUPPORTED;
-}
-
 // ------------------------------------------------------------------------------------ launchers
 template <int NTP>
 static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                         int unit0, int nunits, int center, const void *idx, const void *base, hipStream_t st) {
+                         int unit0, int nunits, int center, const void *idx, const void *base, int f64,
+                         const int32_t *only, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
-#define SVDQ_LAUNCH_GRAM(M, AUX)                                                                                   \
-    hipLaunchKernelGGL((k_gram<NTP, M>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, rows_dev, \
-                       pl->n_tasks, center, gram_part, unit0, (const void *const *)(const void *)(AUX))
-    if (idx) SVDQ_LAUNCH_GRAM(1, idx);
-    else if (base) SVDQ_LAUNCH_GRAM(2, base);
-    else SVDQ_LAUNCH_GRAM(0, nullptr);
+#define SVDQ_LAUNCH_GRAM(M, F, AUX)                                                                                  \
+    hipLaunchKernelGGL((k_gram<NTP, M, F>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, rows_dev, \
+                       pl->n_tasks, center, gram_part, unit0, (const void *const *)(const void *)(AUX), only)
+    if (f64) {
+        if (idx) SVDQ_LAUNCH_GRAM(1, true, idx);
+        else if (base) SVDQ_LAUNCH_GRAM(2, true, base);
+        else SVDQ_LAUNCH_GRAM(0, true, nullptr);
+    } else {
+        if (idx) SVDQ_LAUNCH_GRAM(1, false, idx);
+        else if (base) SVDQ_LAUNCH_GRAM(2, false, base);
+        else SVDQ_LAUNCH_GRAM(0, false, nullptr);
+    }
 #undef SVDQ_LAUNCH_GRAM
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
+// f64: accumulate the products with v_mfma_f64_16x16x4_f64 (exact) instead of fp32 MFMA; only: NULL, or a device
+// table [n_params] -- units of parameters whose entry is 0 return at once (the refinement pass of N > 16)
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                     int unit0, int nunits, int center, const void *idx, const void *base, hipStream_t st) {
+                     int unit0, int nunits, int center, const void *idx, const void *base, int f64,
+                     const int32_t *only, hipStream_t st) {
     if (idx && base) {
         svdq_set_error("gather mode and minus-base mode cannot be combined");
         return SVDQ_EUNSUPPORTED;
     }
+#define SVDQ_GRAM_CASE(n) \
+    case n: return launch_gram_t<n>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, f64, only, st)
     switch (pl->ntp) {
-        case 4: return launch_gram_t<4>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
-        case 8: return launch_gram_t<8>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
-        case 12: return launch_gram_t<12>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
-        case 16: return launch_gram_t<16>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
-        case 20: return launch_gram_t<20>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
-        case 24: return launch_gram_t<24>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
-        case 28: return launch_gram_t<28>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
-        case 32: return launch_gram_t<32>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, st);
+        SVDQ_GRAM_CASE(4); SVDQ_GRAM_CASE(8); SVDQ_GRAM_CASE(12); SVDQ_GRAM_CASE(16);
+        SVDQ_GRAM_CASE(20); SVDQ_GRAM_CASE(24); SVDQ_GRAM_CASE(28); SVDQ_GRAM_CASE(32);
     }
+#undef SVDQ_GRAM_CASE
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;
 }

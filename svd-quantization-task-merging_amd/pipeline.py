@@ -258,8 +258,7 @@ class CompressPlan:
         L, P, N, S = self.layout, self.P, self.N, self.S
         status = int(host[L.status_off:L.status_off + 4].view(np.int32)[0])
         if status != 0:
-            raise RuntimeError(f"svdq_compress reported status {status}: the fused schedule gave up waiting for a "
-                               "parameter's eigen-stage; results are invalid")
+            raise RuntimeError(f"svdq_compress reported status {status}; results are invalid")
 
         def view(off, dtype, shape):
             n = int(np.prod(shape)) * np.dtype(dtype).itemsize

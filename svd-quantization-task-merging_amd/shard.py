@@ -1,13 +1,14 @@
 """
 Multi-GPU sharding of the hot path: parameter tensors are independent units,
 so ranks take disjoint sets of tensors with NO data-path collective; only the packed small-artifact
-buffers (ranks, sigma, coefficients, codes: KB..MB) are exchanged at the end.  The fp16 bases stay
-resident on their owning GPU (gathering them costs more than computing them: SURVEY.md 8e).
+buffers (ranks, sigma, coefficients, codes: KB..MB) are exchanged at the end of a step.  The fp16 bases stay
+resident on their owning GPU (gathering them costs more than computing them: SURVEY.md 8e); ``BasisGather``
+exists so that cost can be measured and reported on its own.
 One process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU for tests).
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -28,20 +29,47 @@ def partition_lpt(rows: Sequence[int], world_size: int) -> List[List[int]]:
     return out
 
 
-def gather_small(small: torch.Tensor, group=None) -> List[torch.Tensor]:
-    """All ranks contribute their packed small-artifact byte buffer; every rank gets the list
-    (padded to the longest, then trimmed).  One all_gather of a few hundred KB."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    n = torch.tensor([small.numel()], dtype=torch.int64, device=small.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    mx = int(max(int(s.item()) for s in sizes))
-    padded = torch.zeros(mx, dtype=torch.uint8, device=small.device)
-    padded[:small.numel()] = small
-    outs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(outs, padded, group=group)
-    return [o[:int(s.item())] for o, s in zip(outs, sizes)]
+class RaggedGather:
+    """All-gather of one byte buffer per rank whose lengths differ between ranks but not between steps.
+
+    Plan time (constructor): the lengths are exchanged ONCE and the padded send / receive buffers are allocated.
+    Step time (``run``): one device-side copy into the send slot and ONE ``all_gather_into_tensor`` -- no size
+    exchange, no allocation, no host synchronisation, so it can sit inside a timed (or graph-captured) region.
+    ``views()`` returns rank r's bytes as a slice of the receive buffer (valid after the collective has run on
+    the stream)."""
+
+    def __init__(self, nbytes_local: int, device, group=None, align: int = 256):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.nbytes = int(nbytes_local)
+        n = torch.tensor([self.nbytes], dtype=torch.int64, device=device)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n, group=group)                       # the only size exchange, at plan time
+        self.sizes = [int(s.item()) for s in sizes]
+        self.stride = (max(self.sizes) + align - 1) // align * align
+        self.send = torch.zeros(max(self.stride, 1), dtype=torch.uint8, device=device)
+        self.recv = torch.empty(max(self.stride, 1) * self.world, dtype=torch.uint8, device=device)
+
+    def run(self, buf: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+        if buf.numel() != self.nbytes:
+            raise ValueError(f"buffer has {buf.numel()} bytes, the gather was planned for {self.nbytes}")
+        self.send[:self.nbytes].copy_(buf.view(torch.uint8).reshape(-1), non_blocking=True)
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        return self.recv
+
+    def views(self) -> List[torch.Tensor]:
+        return [self.recv[r * self.stride:r * self.stride + self.sizes[r]] for r in range(self.world)]
+
+
+def gather_small(small: torch.Tensor, group=None, plan: Optional[RaggedGather] = None) -> List[torch.Tensor]:
+    """All ranks contribute their packed small-artifact byte buffer; every rank gets the list.  Pass the
+    ``RaggedGather`` built at plan time to keep the step free of size exchanges and allocations; without one it
+    is built here (convenience for one-off calls)."""
+    rg = plan if plan is not None else RaggedGather(small.numel(), small.device, group)
+    rg.run(small)
+    return rg.views()
 
 
 def all_reduce_gram(gram: torch.Tensor, group=None) -> torch.Tensor:

@@ -17,6 +17,8 @@ Fixture families (all .npz, loadable with allow_pickle=False):
   rtvq_large.npz  config #1: RTVQQuantizer(4,2) on a 768x768 tensor (seeded; checksums)
   basis_*.npz     construct_basis -> .half() -> compress_single_task -> dequantize ->
                   reconstruct_from_coefficients (the four-call parity chain)
+  spectrum_*.npz  the same chain on inputs whose spectrum reaches down to 3e-6 sigma_0, on exactly dependent tasks
+                  and with the cumulative energy 5e-5 below / above the threshold (with fp64 singular values beside)
   config1.npz     N=2, one [768,768], center False/True (the F4 NaN case recorded as such)
   masks.npz       combine_masks / apply_mask_to_tensor / get_unmasked_portion /
                   reconstruct_from_masked / construct_masked_basis(include_noise)
@@ -644,6 +646,54 @@ def gen_cluster():
     save("cluster.npz", **out)
 
 
+
+# ------------------------------------------------------------------------------- graded spectra
+def _structured(D, N, sigmas, seed, common_mean=0.0):
+    """T = Q diag(sigmas) Z^T (Q: D x N and Z: N x N orthonormal, built in fp64) cast to fp32, plus an optional
+    common per-row offset so that centring has something to remove."""
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, N)))
+    Z, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    T = (Q * np.asarray(sigmas, dtype=np.float64)) @ Z.T
+    if common_mean:
+        T = T + common_mean * rng.standard_normal((D, 1))
+    return [torch.from_numpy(np.ascontiguousarray(T[:, j]).astype(np.float32)) for j in range(N)]
+
+
+def _s64(deltas, center):
+    """fp64 singular values of exactly the matrix the reference factorises (fp32 stack, fp32 centring)."""
+    T = torch.stack(deltas, dim=1)
+    if center:
+        T = T - T.mean(dim=1, keepdim=True)
+    return np.linalg.svd(T.double().numpy(), compute_uv=False)
+
+
+def gen_spectrum():
+    """Chains whose spectrum reaches far below sigma_0: graded singular values, exactly dependent
+    tasks, and a cumulative energy that sits 5e-5 below / above the threshold."""
+    graded8 = [1.0, 1e-1, 1e-2, 1e-3, 1e-4, 3e-5, 1e-5, 3e-6]
+    graded16 = [10.0 ** (-i / 3.0) for i in range(16)]
+    specs = []
+    specs.append(("spectrum_graded_n8", _structured(6000, 8, graded8, 101), 0.99999, False))
+    specs.append(("spectrum_graded_n8c", _structured(6000, 8, graded8, 102, common_mean=0.3), 0.99999, True))
+    specs.append(("spectrum_graded_n16", _structured(5000, 16, graded16, 103), 0.99995, False))
+    # exactly dependent tasks: t2 = t0, t4 = t0 + t1 -> rank 4 of 6
+    base = _structured(5000, 4, [1.0, 0.5, 0.25, 0.125], 104)
+    dep = [base[0], base[1], base[0].clone(), base[2], base[0] + base[1], base[3]]
+    specs.append(("spectrum_rankdef_n6", dep, 0.9, False))
+    # two identical tasks, centred (VERDICT: "a rank-deficient input (two identical tasks)")
+    b5 = _structured(5000, 5, [1.0, 0.6, 0.4, 0.3, 0.2], 105, common_mean=0.2)
+    specs.append(("spectrum_twins_n6c", [b5[0], b5[1], b5[2], b5[1].clone(), b5[3], b5[4]], 0.9, True))
+    # cumulative energy of the first two directions = 0.9 -/+ 5e-5
+    for tag, e1 in (("below", 0.29995), ("above", 0.30005)):
+        en = [0.6, e1, 0.05 + (0.3 - e1), 0.03, 0.01, 0.006, 0.003, 0.001]
+        specs.append((f"spectrum_thresh_{tag}_n8", _structured(6000, 8, np.sqrt(en), 106), 0.9, False))
+    for name, deltas, thr, center in specs:
+        out = basis_chain(deltas, thr, None, center, True, 4, 2, store_inputs=True, store_full=True)
+        out["S_f64"] = _s64(deltas, center)
+        save(name + ".npz", **out)
+        print("   S  ", out["S"], " k", int(out["k"]), " energy", float(out["energy_retained"]))
+
 # ------------------------------------------------------------------------------- rank KATs
 def gen_rank():
     out = {}
@@ -677,6 +727,7 @@ if __name__ == "__main__":
     gen_rtvq_large()
     gen_rank()
     gen_basis()
+    gen_spectrum()
     gen_config1()
     gen_masks()
     gen_pipeline()

@@ -144,8 +144,11 @@ def test_full_model_masked_union_gather():
         union = torch.stack(per_task[p]).any(dim=0)
         assert torch.equal(outs[p].view(torch.bool), union) and int(union.sum()) == int(counts[p])
         sel = [v[union].contiguous() for v in views[p]]          # torch's own boolean-index compaction
-        ref = CompressPlan([sel[0].numel()], N, **kw)
-        ref.run(ref.pointer_table([sel]))
+        # same declared size as in the gather plan (the unit decomposition, and with it the fixed order of the fp64
+        # partial sums, follows the plan's declared rows), actual size through rows_dev
+        ref = CompressPlan([rows[p]], N, **kw)
+        pad = [torch.cat([x, torch.zeros(rows[p] - x.numel(), device=dev)]) for x in sel]
+        ref.run(ref.pointer_table([pad]), torch.tensor([sel[0].numel()], dtype=torch.int64, device=dev))
         sr = ref.fetch_small()
         k, r, D = int(sr.k[0]), int(sr.r[0]), int(sr.rows[0])
         assert (k, r, D) == (int(sm.k[p]), int(sm.r[p]), int(sm.rows[p]))

@@ -126,7 +126,11 @@ def _deltas_for(g):
     return ds
 
 
-@pytest.mark.parametrize("name", BASIS_FIXTURES + ["basis_d65536_n8"])
+SPECTRUM_FIXTURES = ["spectrum_graded_n8", "spectrum_graded_n8c", "spectrum_graded_n16", "spectrum_rankdef_n6",
+                     "spectrum_twins_n6c", "spectrum_thresh_below_n8", "spectrum_thresh_above_n8"]
+
+
+@pytest.mark.parametrize("name", BASIS_FIXTURES + ["basis_d65536_n8"] + SPECTRUM_FIXTURES)
 def test_basis_chain_vs_reference(name):
     """Same machine, same LAPACK: the oracle must reproduce the reference's chain exactly
     for integers and to BLAS-reduction-order tolerance for floats."""

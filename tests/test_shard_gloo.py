@@ -51,6 +51,22 @@ def _worker(rank, world, port, q):
         for r, buf in enumerate(got):
             want = torch.tensor([i % 251 for i in parts[r] for _ in range(3)], dtype=torch.uint8)
             assert torch.equal(buf, want), r
+        # the planned form bench.py uses inside its timed region: sizes exchanged once in the constructor, then one
+        # all_gather_into_tensor per step into the same preallocated buffer -- new contents every step
+        rg = shard.RaggedGather(payload.numel(), "cpu")
+        assert rg.sizes == [3 * len(p) for p in parts]
+        recv_ptr = rg.recv.data_ptr()
+        for step in range(3):
+            rg.run((payload + step).to(torch.uint8))
+            assert rg.recv.data_ptr() == recv_ptr                    # nothing reallocated between steps
+            for r, buf in enumerate(rg.views()):
+                want = torch.tensor([(i % 251 + step) % 256 for i in parts[r] for _ in range(3)], dtype=torch.uint8)
+                assert torch.equal(buf, want), (step, r)
+        try:
+            rg.run(payload[:-1])
+            raise AssertionError("a buffer of another length must be refused")
+        except ValueError:
+            pass
         loads = [sum(rows[i] for i in p) for p in parts]
         tot = torch.tensor([float(sum(rows[i] for i in mine))])
         dist.all_reduce(tot)
@@ -115,3 +131,19 @@ def test_partition_properties():
     assert tot == {"ViT-B-32": 87849216, "ViT-B-16": 86192640, "ViT-L-14": 303966208}
     assert {m: len(workloads.vit_visual_shapes(m)) for m in workloads.VIT_SPECS} == \
         {"ViT-B-32": 152, "ViT-B-16": 152, "ViT-L-14": 296}
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` without a launcher spawns its ranks itself; with fewer than N GPUs visible (none
+    here) it must say so and exit non-zero BEFORE touching a GPU instead of silently running one rank."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SVDQ_DIST_BACKEND"):
+        env.pop(k, None)
+    if torch.cuda.device_count() >= 4:
+        pytest.skip("needs a machine with fewer than 4 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "needs 4 GPUs" in r.stderr
