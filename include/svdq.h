@@ -325,6 +325,12 @@ int svdq_recon_error(const void *u_high_dev, const void *u_low_dev, int32_t u_fp
                      int32_t nl, const float *coef_dev, const float *mean_dev, const float *recon_dev,
                      const float *orig_dev, double *out6_dev, void *work_dev, void *stream);
 
+/* ---- measurement aid (no reference counterpart; SURVEY.md section 8d asks for "a measured device-copy ceiling on
+ *      the box" beside the 8 TB/s specification): plain streaming kernels with the access shape of the two passes.
+ *      mode 0: read `bytes` from src_dev (dst_dev receives 32 KiB of per-wave sums); mode 1: copy `bytes`;
+ *      mode 2: read `bytes`, write 5/8 of that (pass 2's read : write mix at N = 8).  dst_dev must hold `bytes`. */
+int svdq_hbm_probe(int32_t mode, const void *src_dev, void *dst_dev, int64_t bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,7 @@ SIGNATURES = {
     "svdq_recon_error": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_mask_expand": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "svdq_hbm_probe": (c_int32, [c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

@@ -13,7 +13,16 @@ import torch
 from .pipeline import (BatchResult, CompressPlan, basis_dict, prepare_vector, resolve_device, task_artifact)
 from . import mask_loader as ml
 
-_BATCH_KEY = "_svdq_batch"
+
+
+def _resident(tensors, dev) -> bool:
+    """All tensors already satisfy the ABI's input contract except (possibly) for their shape: fp32, contiguous, on
+    ``dev``, 16-byte aligned -- then the plan can take their addresses as they are (pointer_table re-checks)."""
+    f32 = torch.float32
+    for t in tensors:
+        if t.dtype is not f32 or t.device != dev or not t.is_contiguous() or t.requires_grad or t.data_ptr() & 15:
+            return False
+    return True
 
 
 def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks: Optional[Dict[str, torch.Tensor]],
@@ -51,7 +60,8 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
             if mask is not None and mask.shape == deltas[0].shape and mask.numel() > 0:
                 masked_by_n.setdefault(len(present), []).append((name, present, deltas, mask))
             else:
-                vs = [prepare_vector(d, dev) for d in deltas]
+                vs = [d if d.dim() == 1 else prepare_vector(d, dev) for d in deltas] if _resident(deltas, dev) \
+                    else [prepare_vector(d, dev) for d in deltas]
                 if vs[0].numel() == 0:
                     continue
                 groups.setdefault((len(present), False), []).append(
@@ -121,40 +131,90 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
                 slot = bases.setdefault(e["name"], {"masked": None, "noise": None})
                 if int(small.rows[i]) <= 0:
                     continue
-                b = basis_dict(plan, small, i)
-                b[_BATCH_KEY] = (batch, i)
-                slot[e["region"]] = b
+                # the views into the packed basis buffer are made when somebody looks at them
+                slot[e["region"]] = LazyArtifacts((lambda pl=plan, sm=small, q=i: basis_dict(pl, sm, q)), (batch, i))
     # parameters whose masked region was skipped (mask.sum() < svd_min_mask_size) have no basis
     # entry at all in the reference (cli.py:343 guards the assignment)
     return {n: b for n, b in bases.items() if b["masked"] is not None}
+
+
+class LazyArtifacts(dict):
+    """A dictionary of one parameter -- {task: {"masked": art|None, "unmasked": art|None}} in ``compressed_all``, or a
+    basis {U_high, U_low, singular_values, k, mean, energy_retained, D, N} in ``bases`` -- assembled from the packed
+    buffers of the batched run on first access.  It IS a dict (isinstance, iteration, json, equality all behave); a caller that only
+    passes the structure on (or inspects a few parameters) does not pay for assembling ~10^4 nested payload
+    dictionaries per model.  storage.save_compressed_coefficients writes plain dicts (as the reference's writer
+    does: it rebuilds the per-task level); pickled / torch.saved directly it comes back as a collections.OrderedDict,
+    the one mapping type the weights-only unpickler admits besides dict itself."""
+    __slots__ = ("_fill", "_batch")
+
+    def __init__(self, fill, batch=None):
+        super().__init__()
+        self._fill = fill
+        self._batch = batch      # (BatchResult, index): where this parameter's results live
+
+    def _ensure(self):
+        f = self._fill
+        if f is not None:
+            self._fill = None
+            super().update(f())
+
+    def __reduce__(self):
+        from collections import OrderedDict
+        self._ensure()
+        return (OrderedDict, (), None, None, iter(dict.items(self)))
+
+    def __repr__(self):
+        self._ensure()
+        return super().__repr__()
+
+
+def _lazy(name):
+    def method(self, *a, **kw):
+        self._ensure()
+        return getattr(dict, name)(self, *a, **kw)
+    method.__name__ = name
+    return method
+
+
+for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__eq__", "__ne__", "__setitem__", "__delitem__",
+           "__or__", "__ror__", "keys", "values", "items", "get", "pop", "popitem", "setdefault", "update", "copy",
+           "__bool__" if hasattr(dict, "__bool__") else "__len__"):
+    setattr(LazyArtifacts, _n, _lazy(_n))
 
 
 def artifacts_from_batch(name: str, basis: Dict, task_vectors, config) -> Optional[Dict]:
     """{task: {"masked": art|None, "unmasked": art|None}} from the fused run, or None if this basis
     did not come from ``build_bases`` (then compress.py runs the per-task route)."""
     bm = basis.get("masked")
-    if bm is None or _BATCH_KEY not in bm:
+    if bm is None or getattr(bm, "_batch", None) is None:
         return None
-    batch, i = bm[_BATCH_KEY]
+    batch, i = bm._batch
     want_bits = getattr(config, "svd_low_bits_by_param", None)
     want_bits = int(want_bits(name)) if want_bits else config.svd_low_bits
     if (batch.plan.bits_of(i), batch.plan.S) != (want_bits, config.svd_rtvq_stages):
         return None
-    out = {}
     tasks_i = batch.task_names[i]
     bn = basis.get("noise") if config.svd_include_noise else None
-    for t in task_vectors.keys():
-        if name not in task_vectors[t]:
-            continue
-        art = {"masked": None, "unmasked": None}
-        if t in tasks_i:
-            art["masked"] = task_artifact(batch.plan, batch.small, i, tasks_i.index(t))
-        if bn is not None and _BATCH_KEY in bn:
-            nb, j = bn[_BATCH_KEY]
-            if t in nb.task_names[j]:
-                art["unmasked"] = task_artifact(nb.plan, nb.small, j, nb.task_names[j].index(t))
-        out[t] = art
-    return out
+    have = [t for t in task_vectors.keys() if name in task_vectors[t]]
+
+    def fill():
+        out = {}
+        pos = {t: j for j, t in enumerate(tasks_i)}
+        npos = None
+        if bn is not None and getattr(bn, "_batch", None) is not None:
+            nb, j = bn._batch
+            npos = {t: q for q, t in enumerate(nb.task_names[j])}
+        for t in have:
+            art = {"masked": None, "unmasked": None}
+            if t in pos:
+                art["masked"] = task_artifact(batch.plan, batch.small, i, pos[t])
+            if npos is not None and t in npos:
+                art["unmasked"] = task_artifact(nb.plan, nb.small, j, npos[t])
+            out[t] = art
+        return out
+
+    return LazyArtifacts(fill)
 
 
 def run_basis_and_compress(task_vectors, combined_masks, config, device="cuda") -> Tuple[Dict, Dict]:

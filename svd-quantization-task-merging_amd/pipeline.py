@@ -34,7 +34,11 @@ def resolve_device(device) -> torch.device:
 
 
 def prepare_vector(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
-    """fp32, contiguous, flat, on ``dev``, 16-byte aligned (the only input contract of the ABI)."""
+    """fp32, contiguous, flat, on ``dev``, 16-byte aligned (the only input contract of the ABI).  A tensor that
+    already is all of that comes back as it is (a model's worth of task tensors makes this the hot host call)."""
+    if (t.dtype is torch.float32 and t.dim() == 1 and t.device == dev and t.is_contiguous()
+            and not t.requires_grad and t.data_ptr() % 16 == 0):
+        return t
     v = t.detach()
     if v.device != dev or v.dtype != torch.float32:
         v = v.to(device=dev, dtype=torch.float32)
@@ -120,6 +124,17 @@ class CompressPlan:
         self._keep = None
 
     # ---- lifetime
+    def fresh_outputs(self):
+        """New output buffers (small, basis, mean) for the next run; the previous ones stay with whoever holds them.
+        The plan's tables and workspace are reused (runs are ordered on the stream they are enqueued on)."""
+        dev = self.device
+        self.small = torch.zeros(self.sizes.small_bytes, dtype=torch.uint8, device=dev)
+        if self.basis is not None:
+            self.basis = torch.empty(self.sizes.basis_bytes, dtype=torch.uint8, device=dev)
+        if self.mean is not None:
+            self.mean = torch.empty(self.sizes.mean_floats, dtype=torch.float32, device=dev)
+        self._typed = None
+
     def bits_of(self, p: int) -> int:
         return self.bits_list[p] if self.bits_list is not None else self.bits
 
@@ -139,17 +154,20 @@ class CompressPlan:
         """vectors[p][t] -> device int64 tensor [P*N] of data pointers (parameter-major)."""
         assert len(vectors) == self.P
         ptrs = []
+        f32, dev, N, rows = torch.float32, self.device, self.N, self.rows
         for p, vs in enumerate(vectors):
-            if len(vs) != self.N:
-                raise ValueError(f"parameter {p}: expected {self.N} task vectors, got {len(vs)}")
+            if len(vs) != N:
+                raise ValueError(f"parameter {p}: expected {N} task vectors, got {len(vs)}")
+            need = rows[p]
             for v in vs:
-                if v.dtype != torch.float32 or not v.is_contiguous() or v.device != self.device:
+                a = v.data_ptr()
+                if v.dtype is not f32 or v.device != dev or not v.is_contiguous():
                     raise ValueError("task vectors must be contiguous fp32 tensors on the plan's device")
-                if v.data_ptr() % 16 != 0:
+                if a & 15:
                     raise ValueError("task vector base address must be 16-byte aligned")
-                if v.numel() < self.rows[p]:
-                    raise ValueError(f"parameter {p}: vector has {v.numel()} elements, plan says {self.rows[p]}")
-                ptrs.append(v.data_ptr())
+                if v.numel() < need:
+                    raise ValueError(f"parameter {p}: vector has {v.numel()} elements, plan says {need}")
+                ptrs.append(a)
         self._keep = vectors  # the table holds raw addresses: keep the owners alive
         return torch.tensor(ptrs, dtype=torch.int64).to(self.device)
 
@@ -275,36 +293,62 @@ class CompressPlan:
     def basis_tensors(self, p: int, k: int, r: int, rows: int) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
         """Zero-copy views (U_high [rows,k], U_low [rows,r-k], mean [rows,1] | None) of parameter p."""
         es = 2 if self.fp16 else 4
-        dt = torch.float16 if self.fp16 else torch.float32
+        typed = self._typed_basis()
         base = self.slab_off[p]
         hi_bytes = rows * k * es
         lo_off = base + (hi_bytes + 255) // 256 * 256
         nl = r - k
-        U_high = self.basis[base:base + hi_bytes].view(dt).view(rows, k)
+        # one as_strided per view (slab offsets are 256-byte aligned, so they are whole elements)
+        U_high = torch.as_strided(typed, (rows, k), (k, 1), base // es)
         if nl > 0:
-            U_low = self.basis[lo_off:lo_off + rows * nl * es].view(dt).view(rows, nl)
+            U_low = torch.as_strided(typed, (rows, nl), (nl, 1), lo_off // es)
         else:
-            U_low = torch.empty((rows, 0), dtype=dt, device=self.device)
+            U_low = torch.empty((rows, 0), dtype=typed.dtype, device=self.device)
         mean = None
         if self.center:
-            mean = self.mean[self.mean_off[p]:self.mean_off[p] + rows].view(rows, 1)
+            mean = torch.as_strided(self.mean, (rows, 1), (1, 1), self.mean_off[p])
         return U_high, U_low, mean
+
+    def _typed_basis(self) -> torch.Tensor:
+        """The packed basis buffer viewed in its element type (cached; re-made when the buffer is replaced)."""
+        tb = getattr(self, "_typed", None)
+        if tb is None or tb[0] is not self.basis:
+            dt = torch.float16 if self.fp16 else torch.float32
+            n = self.basis.numel() // (2 if self.fp16 else 4)
+            tb = (self.basis, self.basis[:n * (2 if self.fp16 else 4)].view(dt))
+            self._typed = tb
+        return tb[1]
 
 
 # ------------------------------------------------------------------------------------------------
 class _HostViews:
-    """torch views of the host copy of the small artifacts, split ONCE into per-row tuples: assembling the
-    reference's nested payload dictionaries for a ViT-L model touches ~10^4 scalars and rows, and one
-    torch.tensor() / indexing call per item costs more than the GPU work of the whole model."""
+    """torch views of the host copy of the small artifacts.  Assembling the reference's nested payload dictionaries
+    for a ViT-L model touches ~10^4 scalars and rows, and one torch.tensor() / indexing call per item costs more than
+    the GPU work of the whole model: everything is split with a handful of unbind() calls per field (scalars) or
+    per parameter (rows narrowed to the parameter's n_low / k)."""
 
     def __init__(self, sm: SmallArtifacts):
         P, N, S = sm.scale.shape
-        self.N, self.S = N, S
+        self.P, self.N, self.S = P, N, S
         self.scale = torch.from_numpy(np.ascontiguousarray(sm.scale)).reshape(-1).unbind(0)
         self.zero_point = torch.from_numpy(np.ascontiguousarray(sm.zero_point)).reshape(-1).unbind(0)
         self.rnorm = np.ascontiguousarray(sm.residual_norm).reshape(-1).tolist()
-        self.codes = torch.from_numpy(np.ascontiguousarray(sm.codes)).reshape(P * N * S, N).unbind(0)
-        self.c_high = torch.from_numpy(np.ascontiguousarray(sm.c_high)).reshape(P * N, N).unbind(0)
+        self.codes = torch.from_numpy(np.ascontiguousarray(sm.codes))          # [P, N, S, N]
+        self.c_high = torch.from_numpy(np.ascontiguousarray(sm.c_high))        # [P, N, N]
+        self.k = sm.k.tolist()
+        self.r = sm.r.tolist()
+        self._per_param = {}
+
+    def param(self, p: int):
+        """(c_high rows [N] of length k, code rows [N*S] of length n_low) of parameter p, as tuples of views."""
+        got = self._per_param.get(p)
+        if got is None:
+            k, nl = self.k[p], self.r[p] - self.k[p]
+            ch = self.c_high[p, :, :k].unbind(0)
+            cd = self.codes[p, :, :, :nl].reshape(self.N * self.S, nl).unbind(0) if nl > 0 else ()
+            got = (ch, cd)
+            self._per_param[p] = got
+        return got
 
 
 def _views(sm: SmallArtifacts) -> _HostViews:
@@ -320,11 +364,12 @@ def quant_payloads(sm: SmallArtifacts, p: int, t: int, nl: int, bits: int, stage
     payloads = []
     if nl > 0:
         hv = _views(sm)
+        cd = hv.param(p)[1]
         base = (p * hv.N + t) * hv.S
         for s in range(stages):
             payloads.append({
                 "stage": s,
-                "quantized": hv.codes[base + s][:nl],
+                "quantized": cd[t * hv.S + s],
                 "scale": hv.scale[base + s],
                 "zero_point": hv.zero_point[base + s],
                 "residual_norm": hv.rnorm[base + s],
@@ -345,9 +390,9 @@ def basis_dict(plan: CompressPlan, sm: SmallArtifacts, p: int) -> Dict:
 
 def task_artifact(plan: CompressPlan, sm: SmallArtifacts, p: int, t: int) -> Dict:
     """compress_single_task return layout (reference compress.py:53-56); CPU tensors."""
-    k, r = int(sm.k[p]), int(sm.r[p])
-    return {"c_high_fp16": _views(sm).c_high[p * plan.N + t][:k],
-            "c_low_quant": quant_payloads(sm, p, t, r - k, plan.bits_of(p), plan.S)}
+    hv = _views(sm)
+    return {"c_high_fp16": hv.param(p)[0][t],
+            "c_low_quant": quant_payloads(sm, p, t, hv.r[p] - hv.k[p], plan.bits_of(p), plan.S)}
 
 
 class BatchResult:

@@ -63,7 +63,7 @@ def load_basis(param_name: str, artifact_dir: str, device: str = "cpu") -> Dict:
     path = os.path.join(artifact_dir, "basis", f"{_safe(param_name)}.pt")
     if not os.path.exists(path):
         raise FileNotFoundError(f"Basis file not found: {path}")
-    return torch.load(path, map_location=device, weights_only=False)
+    return torch.load(path, map_location=device, weights_only=True)   # tensors, scalars, None, dict: nothing executes
 
 
 def save_compressed_coefficients(compressed: Dict[str, Dict[str, Dict]], output_dir: str):
@@ -87,7 +87,8 @@ def load_compressed_coefficients(param_name: str, artifact_dir: str, device: str
     path = os.path.join(artifact_dir, "coeffs", f"{_safe(param_name)}.pt")
     if not os.path.exists(path):
         raise FileNotFoundError(f"Coefficients file not found: {path}")
-    return torch.load(path, map_location=device, weights_only=False)
+    # tensors, int / float / str / None, dict / list and torch.Size only: the weights-only unpickler accepts all of it
+    return torch.load(path, map_location=device, weights_only=True)
 
 
 def _serializable(obj):
@@ -125,8 +126,11 @@ def save_config(config, output_dir: str):
     os.makedirs(output_dir, exist_ok=True)
     with open(os.path.join(output_dir, "config.json"), "w") as f:
         d = asdict(config)
-        if callable(d.get("svd_low_bits_by_param")):      # a name -> bits function is not serialisable
-            d["svd_low_bits_by_param"] = None
+        # the key set must be exactly the reference dataclass's: its load_config does SVDHybridConfig(**json)
+        # (storage.py:283-303) and raises TypeError on anything else.  The mixed-width extension is a function of
+        # the parameter name and not serialisable anyway; the widths actually used are in every coeffs/*.pt
+        # ("c_low_quant"["num_bits"]).
+        d.pop("svd_low_bits_by_param", None)
         json.dump(d, f, indent=2)
 
 

@@ -60,6 +60,30 @@ def _mask_select(x: torch.Tensor, mask: torch.Tensor, invert: bool) -> torch.Ten
     return _select(x, mask, invert)
 
 
+# Plans (device tables + workspace) are kept per (sizes, N, settings, device, stream): a repeated call with the same
+# shapes creates nothing and does not synchronise -- its kernels are ordered behind the previous call's on the same
+# stream, which is also what makes sharing the workspace safe.  Output buffers are fresh per call (the caller owns them).
+_PLAN_CACHE: "dict[tuple, CompressPlan]" = {}
+_PLAN_CACHE_MAX = 8
+
+
+def _cached_plan(rows, n_tasks, energy, max_rank, center, fp16, bits, stages, dev) -> CompressPlan:
+    key = (tuple(rows), n_tasks, float(energy), int(max_rank), bool(center), bool(fp16), int(bits), int(stages),
+           dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    plan = _PLAN_CACHE.pop(key, None)
+    if plan is None:
+        plan = CompressPlan(rows, n_tasks, energy_threshold=energy, max_rank=max_rank if max_rank > 0 else None,
+                            center=center, fp16=fp16, low_bits=bits, rtvq_stages=stages, device=dev)
+        while len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+            old = _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+            torch.cuda.synchronize(dev)                 # its workspace may still be in use
+            old.close()
+    else:
+        plan.fresh_outputs()
+    _PLAN_CACHE[key] = plan                              # most recently used last
+    return plan
+
+
 def _compress(deltas: List[torch.Tensor], n_tasks: int, energy: float, max_rank: int, center: bool, fp16: bool,
               bits: int, stages: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     if n_tasks < 1 or len(deltas) % n_tasks != 0 or not deltas:
@@ -67,15 +91,12 @@ def _compress(deltas: List[torch.Tensor], n_tasks: int, energy: float, max_rank:
     dev = resolve_device(deltas[0].device)
     P = len(deltas) // n_tasks
     vecs = [[prepare_vector(deltas[p * n_tasks + t], dev) for t in range(n_tasks)] for p in range(P)]
-    plan = CompressPlan([v[0].numel() for v in vecs], n_tasks, energy_threshold=energy,
-                        max_rank=max_rank if max_rank > 0 else None, center=center, fp16=fp16, low_bits=bits,
-                        rtvq_stages=stages, device=dev)
+    plan = _cached_plan([v[0].numel() for v in vecs], n_tasks, energy, max_rank, center, fp16, bits, stages, dev)
     plan.run(plan.pointer_table(vecs))
-    torch.cuda.current_stream(dev).synchronize()       # the plan (tables, workspace) is released on return
+    plan._keep = None      # inputs are only read by the kernels just enqueued; temporaries made by prepare_vector are
+    #                        released stream-ordered by the caching allocator (same stream), so nothing has to be held
     mean = plan.mean if plan.mean is not None else torch.empty(0, dtype=torch.float32, device=dev)
-    out = (plan.small, plan.basis, mean)
-    plan.close()
-    return out
+    return plan.small, plan.basis, mean
 
 
 def _ingest(base: torch.Tensor, finetuned: List[torch.Tensor]) -> List[torch.Tensor]:

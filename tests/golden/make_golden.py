@@ -381,7 +381,7 @@ def gen_pipeline():
 
 
 # ------------------------------------------------------------------------------- merge
-def gen_merge():
+def _merge_run():
     """merge_all_parameters + apply_merged_deltas (merge.py:304-552) over a toy model whose c_low always
     has >= 3 elements (6 tasks, max_rank 2), non-uniform weights, one masked parameter with a noise region."""
     shapes = {"a.weight": (96, 64), "a.bias": (96,), "b.weight": (80, 40)}
@@ -429,6 +429,14 @@ def gen_merge():
     cfg.svd_mask_strategy = "union"
     cfg.svd_weighting = "uniform"
     diag = ref_diag.compute_all_diagnostics(task_vectors, compressed, bases, masks, cfg, device="cpu")
+    return dict(shapes=shapes, tasks=tasks, cfg=cfg, weights=weights, g=g, task_vectors=task_vectors, out=out,
+                masks=masks, bases=bases, compressed=compressed, merged=merged, diag=diag)
+
+
+def gen_merge():
+    r = _merge_run()
+    shapes, tasks, weights, g, task_vectors, out = r["shapes"], r["tasks"], r["weights"], r["g"], r["task_vectors"], r["out"]
+    merged, diag = r["merged"], r["diag"]
 
     def plain(o):
         if isinstance(o, dict):
@@ -463,6 +471,112 @@ def gen_merge():
     out["params"] = np.array(sorted(shapes))
     save("merge.npz", **out)
 
+
+
+# ------------------------------------------------------------------------------- artifact files (f3)
+def _tree(o):
+    """Structure of a saved object: key trees, tensor dtypes / shapes, python types (no values)."""
+    if isinstance(o, torch.Tensor):
+        return {"tensor": str(o.dtype).replace("torch.", ""), "shape": list(o.shape), "device": o.device.type}
+    if isinstance(o, torch.Size):
+        return {"torch.Size": list(o)}
+    if isinstance(o, dict):
+        return {"dict": {str(k): _tree(v) for k, v in o.items()}}
+    if isinstance(o, (list, tuple)):
+        return {type(o).__name__: [_tree(v) for v in o]}
+    return type(o).__name__
+
+
+def _json_tree(o):
+    if isinstance(o, dict):
+        return {k: _json_tree(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_json_tree(v) for v in o]
+    return type(o).__name__
+
+
+def artifact_manifest(root):
+    """Everything that defines the on-disk format of an artifact directory: relative file names, and per file the
+    key tree with dtypes and shapes (.pt, loaded weights-only) or key tree with value types (.json)."""
+    man = {}
+    for dirpath, _, files in os.walk(root):
+        for f in sorted(files):
+            full = os.path.join(dirpath, f)
+            rel = os.path.relpath(full, root).replace(os.sep, "/")
+            if f.endswith(".pt"):
+                man[rel] = _tree(torch.load(full, map_location="cpu", weights_only=True))
+            elif f.endswith(".json"):
+                man[rel] = _json_tree(json.load(open(full)))
+    return man
+
+
+def gen_storage():
+    """The reference's own writer (storage.py:52-338 save_all_artifacts, :392-409 save_merged_model) on the merge.npz
+    run, with a parameter name that needs sanitising.  Stored: the in-memory inputs (tensors + plain python,
+    weights-only loadable), the manifest of what the reference wrote, and the outcome of the reference's
+    load_all_artifacts reading the files THIS package writes from the same inputs."""
+    import tempfile
+    from dataclasses import asdict, fields
+    from src.svd_hybrid import storage as ref_storage
+    from src.svd_hybrid import config as ref_config
+    r = _merge_run()
+    tasks = r["tasks"]
+    rename = {"a.weight": "blk/0\\a.weight"}                 # "/" and "\\" -> "_" (storage.py:72)
+    bases = {rename.get(n, n): b for n, b in r["bases"].items()}
+    compressed = {rename.get(n, n): c for n, c in r["compressed"].items()}
+    diag = dict(r["diag"])
+    diag["per_parameter"] = {rename.get(n, n): v for n, v in diag["per_parameter"].items()}
+    cfg = ref_config.SVDHybridConfig(tasks=tasks, svd_energy_threshold=0.9, svd_max_rank=2, svd_include_noise=True,
+                                     checkpoint_dir="/ckpt", base_model_path="/ckpt/base.pt", device="cpu")
+    with tempfile.TemporaryDirectory() as td:
+        ref_dir = os.path.join(td, "ref")
+        ref_storage.save_all_artifacts(bases, compressed, diag, cfg, ref_dir)
+        ref_storage.save_merged_model(r["merged"], os.path.join(ref_dir, "out"))
+        man_ref = artifact_manifest(ref_dir)
+        # this package's writer on the same inputs, then the REFERENCE's reader on those files
+        import svdq_amd.storage as our_storage
+        import svdq_amd.config as our_config
+        our_cfg = our_config.SVDHybridConfig(**asdict(cfg))
+        our_dir = os.path.join(td, "ours")
+        our_storage.save_all_artifacts(bases, compressed, diag, our_cfg, our_dir)
+        our_storage.save_merged_model(r["merged"], os.path.join(our_dir, "out"))
+        man_ours = artifact_manifest(our_dir)
+        assert man_ours == man_ref, "writer mismatch"
+        back = ref_storage.load_all_artifacts(our_dir, device="cpu")      # SVDHybridConfig(**json) must accept ours
+        assert back["config"] == cfg
+        assert sorted(back["bases"]) == sorted(bases) and sorted(back["compressed"]) == sorted(compressed)
+        for n in bases:
+            for region in ("masked", "noise"):
+                if bases[n].get(region) is None:
+                    continue
+                for key in ("U_high", "U_low", "singular_values", "mean"):
+                    assert torch.equal(back["bases"][n][region][key], bases[n][region][key].cpu())
+            for t in tasks:
+                a = back["compressed"][n][t]["masked"]
+                assert torch.equal(a["c_high_fp16"], compressed[n][t]["masked"]["c_high_fp16"])
+                for pa, pb in zip(a["c_low_quant"]["payloads"], compressed[n][t]["masked"]["c_low_quant"]["payloads"]):
+                    assert torch.equal(pa["quantized"], pb["quantized"]) and torch.equal(pa["scale"], pb["scale"])
+    meta = {"manifest": man_ref, "reference_load_all_artifacts_reads_our_files": True,
+            "config_fields": [f.name for f in fields(ref_config.SVDHybridConfig)],
+            "safe_names": {n: n.replace("/", "_").replace("\\", "_") for n in bases}}
+    with open(os.path.join(HERE, "artifact_manifest.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    def plain(o):                      # numpy scalars (np.mean of the error lists) -> python: weights-only loadable
+        if isinstance(o, dict):
+            return {k: plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)) and not isinstance(o, torch.Size):
+            return [plain(v) for v in o]
+        if isinstance(o, np.integer):
+            return int(o)
+        if isinstance(o, np.floating):
+            return float(o)
+        return o
+    torch.save({"bases": bases, "compressed": compressed, "diagnostics": plain(diag), "config": asdict(cfg),
+                "merged": r["merged"]}, os.path.join(HERE, "artifact_inputs.pt"))
+    chk = torch.load(os.path.join(HERE, "artifact_inputs.pt"), weights_only=True)      # must stay weights-only loadable
+    assert sorted(chk) == ["bases", "compressed", "config", "diagnostics", "merged"]
+    print(f"wrote artifact_manifest.json ({len(man_ref)} files), artifact_inputs.pt "
+          f"({os.path.getsize(os.path.join(HERE, 'artifact_inputs.pt')) / 1024:.0f} KiB)")
 
 # ------------------------------------------------------------------------------- ingest / TVQ
 def gen_tvq():
@@ -677,6 +791,9 @@ def gen_spectrum():
     specs.append(("spectrum_graded_n8", _structured(6000, 8, graded8, 101), 0.99999, False))
     specs.append(("spectrum_graded_n8c", _structured(6000, 8, graded8, 102, common_mean=0.3), 0.99999, True))
     specs.append(("spectrum_graded_n16", _structured(5000, 16, graded16, 103), 0.99995, False))
+    # N > 16: fp32-product Gram first, then the flagged fp64 pass
+    specs.append(("spectrum_graded_n20", _structured(5000, 20, [10.0 ** (-i / 4.0) for i in range(20)], 107),
+                  0.99995, False))
     # exactly dependent tasks: t2 = t0, t4 = t0 + t1 -> rank 4 of 6
     base = _structured(5000, 4, [1.0, 0.5, 0.25, 0.125], 104)
     dep = [base[0], base[1], base[0].clone(), base[2], base[0] + base[1], base[3]]
@@ -732,5 +849,6 @@ if __name__ == "__main__":
     gen_masks()
     gen_pipeline()
     gen_merge()
+    gen_storage()
     gen_cluster()
     gen_tvq()

@@ -44,3 +44,41 @@ def rel_err(a, b):
 
 def as_tensors(arr2d):
     return [torch.from_numpy(np.ascontiguousarray(r)) for r in arr2d]
+
+
+def _tree(o):
+    """Structure of a saved object: key trees, tensor dtypes / shapes, python types (no values)."""
+    if isinstance(o, torch.Tensor):
+        return {"tensor": str(o.dtype).replace("torch.", ""), "shape": list(o.shape), "device": o.device.type}
+    if isinstance(o, torch.Size):
+        return {"torch.Size": list(o)}
+    if isinstance(o, dict):
+        return {"dict": {str(k): _tree(v) for k, v in o.items()}}
+    if isinstance(o, (list, tuple)):
+        return {type(o).__name__: [_tree(v) for v in o]}
+    return type(o).__name__
+
+
+def _json_tree(o):
+    if isinstance(o, dict):
+        return {k: _json_tree(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_json_tree(v) for v in o]
+    return type(o).__name__
+
+
+def artifact_manifest(root):
+    """Same definition as tests/golden/make_golden.py::artifact_manifest (which applied it to the files the
+    reference's writer produced): relative file names, and per file the key tree with dtypes and shapes (.pt, loaded
+    weights-only) or the key tree with value types (.json)."""
+    import json
+    man = {}
+    for dirpath, _, files in os.walk(root):
+        for f in sorted(files):
+            full = os.path.join(dirpath, f)
+            rel = os.path.relpath(full, root).replace(os.sep, "/")
+            if f.endswith(".pt"):
+                man[rel] = _tree(torch.load(full, map_location="cpu", weights_only=True))
+            elif f.endswith(".json"):
+                man[rel] = _json_tree(json.load(open(full)))
+    return man

@@ -267,7 +267,7 @@ def test_basis_chain_vs_reference_vectors(sq, orc, name):
 
 
 # ------------------------------------------------------------------------------- small singular values
-SPECTRUM_FIXTURES = ["spectrum_graded_n8", "spectrum_graded_n8c", "spectrum_graded_n16", "spectrum_rankdef_n6",
+SPECTRUM_FIXTURES = ["spectrum_graded_n8", "spectrum_graded_n8c", "spectrum_graded_n16", "spectrum_graded_n20", "spectrum_rankdef_n6",
                      "spectrum_twins_n6c", "spectrum_thresh_below_n8", "spectrum_thresh_above_n8"]
 
 
@@ -852,7 +852,7 @@ def test_pipeline_vs_reference_vectors(sq, orc):
                                                        b["U_low"], "cuda", mean=b["mean"]).cpu().numpy()
                 n_ok += _compare_recon(rec, g[tag + "recon"], b["U_low"].shape[1])
                 n_all += 1
-                batch, bi = b["_svdq_batch"]
+                batch, bi = b._batch
                 _check_pipeline_quantizer(orc, batch.plan, batch.small, bi)
     assert n_ok >= 0.75 * n_all, (n_ok, n_all)
 

@@ -126,7 +126,7 @@ def _deltas_for(g):
     return ds
 
 
-SPECTRUM_FIXTURES = ["spectrum_graded_n8", "spectrum_graded_n8c", "spectrum_graded_n16", "spectrum_rankdef_n6",
+SPECTRUM_FIXTURES = ["spectrum_graded_n8", "spectrum_graded_n8c", "spectrum_graded_n16", "spectrum_graded_n20", "spectrum_rankdef_n6",
                      "spectrum_twins_n6c", "spectrum_thresh_below_n8", "spectrum_thresh_above_n8"]
 
 

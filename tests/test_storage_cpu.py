@@ -4,10 +4,15 @@ so this runs without a GPU on hand-made dicts shaped like the hot path's outputs
 """
 import json
 import os
+import sys
+from dataclasses import fields
 
 import torch
 
 import svdq_amd as sq
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import GOLDEN, artifact_manifest  # noqa: E402
 
 
 def _basis(D, N, k, mean=True):
@@ -41,11 +46,11 @@ def test_artifact_layout_and_round_trip(tmp_path):
     assert sorted(os.listdir(d)) == ["basis", "coeffs", "config.json", "diagnostics.json"]
     assert sorted(os.listdir(os.path.join(d, "basis"))) == ["blk.0.attn.bias.pt", "blk_0.attn.weight.pt"]
     assert sorted(os.listdir(os.path.join(d, "coeffs"))) == ["blk.0.attn.bias.pt", "blk_0.attn.weight.pt"]
-    raw = torch.load(os.path.join(d, "basis", "blk_0.attn.weight.pt"), weights_only=False)
+    raw = torch.load(os.path.join(d, "basis", "blk_0.attn.weight.pt"), weights_only=True)
     assert sorted(raw.keys()) == ["masked", "noise"]
     assert sorted(raw["masked"].keys()) == sorted(["U_high", "U_low", "singular_values", "k", "mean", "energy_retained", "D", "N"])
     assert raw["masked"]["U_high"].dtype == torch.float16 and raw["masked"]["mean"].shape == (40, 1)
-    assert "noise" not in torch.load(os.path.join(d, "basis", "blk.0.attn.bias.pt"), weights_only=False)
+    assert "noise" not in torch.load(os.path.join(d, "basis", "blk.0.attn.bias.pt"), weights_only=True)
     cj = json.load(open(os.path.join(d, "config.json")))
     assert cj["svd_energy_threshold"] == 0.95 and cj["tasks"] == tasks
     dj = json.load(open(os.path.join(d, "diagnostics.json")))
@@ -76,3 +81,46 @@ def test_artifact_layout_and_round_trip(tmp_path):
             pass
     sq.save_merged_model({"w": torch.ones(2)}, str(tmp_path / "out"))
     assert os.path.exists(tmp_path / "out" / "merged_state_dict.pt")
+
+
+def test_writer_reproduces_the_reference_writers_files(tmp_path):
+    """f3 pinned to the reference writer: tests/golden/make_golden.py::gen_storage ran the reference's
+    save_all_artifacts / save_merged_model (storage.py:52-338, :392-409) on a 3-parameter x 6-task run (one name that
+    needs sanitising, one masked parameter with a noise basis) and recorded the manifest of what it wrote -- file
+    names, key trees, dtypes, shapes, json value types -- plus the in-memory inputs.  This package's writer, fed the
+    same inputs, must produce the same manifest.  (At generation time the reference's load_all_artifacts also read
+    the files this package wrote; that outcome is recorded in the manifest file.)"""
+    meta = json.load(open(os.path.join(GOLDEN, "artifact_manifest.json")))
+    assert meta["reference_load_all_artifacts_reads_our_files"] is True
+    inp = torch.load(os.path.join(GOLDEN, "artifact_inputs.pt"), map_location="cpu", weights_only=True)
+    cfg = sq.SVDHybridConfig(**inp["config"])
+    d = str(tmp_path / "ours")
+    sq.save_all_artifacts(inp["bases"], inp["compressed"], inp["diagnostics"], cfg, d)
+    sq.save_merged_model(inp["merged"], os.path.join(d, "out"))
+    assert artifact_manifest(d) == meta["manifest"]
+    for name, safe in meta["safe_names"].items():
+        assert os.path.exists(os.path.join(d, "basis", safe + ".pt")), (name, safe)
+    # config.json carries exactly the reference dataclass's fields (its load_config does SVDHybridConfig(**json))
+    cj = json.load(open(os.path.join(d, "config.json")))
+    assert sorted(cj) == sorted(meta["config_fields"])
+    ours = {f.name for f in fields(sq.SVDHybridConfig)}
+    assert ours - set(meta["config_fields"]) == {"svd_low_bits_by_param"}      # the one extension, never written
+    # and the weights-only readers take everything back
+    art = sq.load_all_artifacts(d)
+    assert sorted(art["bases"]) == sorted(inp["bases"]) and art["config"] == cfg
+    for n, b in inp["bases"].items():
+        for region in ("masked", "noise"):
+            if b.get(region) is not None:
+                assert torch.equal(art["bases"][n][region]["U_high"], b[region]["U_high"])
+        for t, a in inp["compressed"][n].items():
+            got = art["compressed"][n][t]["masked"]["c_low_quant"]
+            assert got["original_shape"] == a["masked"]["c_low_quant"]["original_shape"]
+            assert torch.equal(got["payloads"][0]["quantized"], a["masked"]["c_low_quant"]["payloads"][0]["quantized"])
+
+
+def test_mixed_width_config_is_not_written(tmp_path):
+    cfg = sq.SVDHybridConfig(tasks=["a", "b"], svd_low_bits_by_param=lambda n: 8 if n.endswith("weight") else 2)
+    sq.storage.save_config(cfg, str(tmp_path))
+    cj = json.load(open(tmp_path / "config.json"))
+    assert "svd_low_bits_by_param" not in cj
+    assert sq.load_config(str(tmp_path)).svd_low_bits == cfg.svd_low_bits

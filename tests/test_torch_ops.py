@@ -44,6 +44,18 @@ def test_ops_match_the_python_layer():
     plan.run(plan.pointer_table(vecs))
     torch.cuda.synchronize()
     assert torch.equal(small, plan.small) and mean.numel() == plan.mean.numel()
+    # a second call with the same shapes reuses the cached plan: no new plan, fresh outputs, same bits, and the
+    # first call's outputs are untouched
+    from svdq_amd import torch_ops
+    n_plans = len(torch_ops._PLAN_CACHE)
+    small_copy = small.clone()
+    small2, basis2, mean2 = torch.ops.svdq.compress([v for vs in vecs for v in vs], N, 0.9, 0, True, True, 4, 2)
+    assert len(torch_ops._PLAN_CACHE) == n_plans and small2.data_ptr() != small.data_ptr()
+    torch.cuda.synchronize()
+    assert torch.equal(small2, small_copy) and torch.equal(small, small_copy)
+    for p, D in enumerate(sizes):              # the packed buffers have uninitialised alignment gaps: compare views
+        o = plan.mean_off[p]
+        assert torch.equal(mean2[o:o + D], mean[o:o + D])
     sm = plan.fetch_small()
     for p, D in enumerate(sizes):
         a = plan.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), D)

@@ -1,12 +1,14 @@
 #!/bin/bash
-# One gpurun call: GPU test-suite, then the bench A/B lines used while developing (outputs under gpurun_out/).
+# One gpurun call: GPU test-suite, then the bench lines used while developing (outputs under gpurun_out/).
+# usage: bash tools/gpu_check.sh [pytest-args...]   (default: the whole -m gpu suite)
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
+if [ "$#" -gt 0 ]; then sel=("$@"); else sel=(tests); fi
+timeout -k 10 1000 python -m pytest "${sel[@]}" -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
 rc=$?
 tail -n 15 gpurun_out/pytest_gpu.log
 [ $rc -ne 0 ] && exit $rc
-for cfg in "" "--gram32" "--tasks 16 --steps 10" "--tasks 16 --steps 10 --gram32" "--tasks 20 --steps 10" "--tasks 20 --steps 10 --gram32"; do
+for cfg in "" "--tasks 20 --steps 10"; do
   tag=$(echo "$cfg" | tr -d ' -')
   timeout -k 10 300 python bench.py --no-cpu $cfg > gpurun_out/bench_$tag.log 2>&1 || { tail -n 5 gpurun_out/bench_$tag.log; exit 1; }
   python - "gpurun_out/bench_$tag.log" "$cfg" <<'PY'
