@@ -243,7 +243,9 @@ int svdq_project(const void *u_high_dev, const void *u_low_dev, int32_t u_fp16, 
 /* ---- masks  (compute_union/intersection/majority_mask mask_loader.py:412-485;
  *      apply_mask_to_tensor / get_unmasked_portion mask_loader.py:651-709).
  *      mask_ptrs_dev: device array [n_masks] of const uint8_t* (torch.bool storage).
- *      svdq_mask_combine writes the combined mask (0/1 bytes) and its popcount.
+ *      svdq_mask_combine writes the combined mask (0/1 bytes) and its popcount.  strategy: SVDQ_MASK_*; for
+ *      SVDQ_MASK_MAJORITY bits 8.. may carry (votes needed + 1) for compute_majority_mask(threshold != 0.5)
+ *      (mask_loader.py:456-485: vote_sum >= threshold * len(masks), compared in fp32); 0 there = threshold 0.5.
  *      svdq_mask_compact: order-preserving compaction of n_src fp32 buffers under one mask
  *      (invert != 0 selects the False positions); count_dev receives the selected count.
  *      work_dev: svdq_mask_work_bytes(numel) bytes. */
@@ -327,7 +329,7 @@ int svdq_recon_error(const void *u_high_dev, const void *u_low_dev, int32_t u_fp
 
 /* ---- measurement aid (no reference counterpart; SURVEY.md section 8d asks for "a measured device-copy ceiling on
  *      the box" beside the 8 TB/s specification): plain streaming kernels with the access shape of the two passes.
- *      mode 0: read `bytes` from src_dev (dst_dev receives 32 KiB of per-wave sums); mode 1: copy `bytes`;
+ *      mode 0: read `bytes` from src_dev (dst_dev receives one float per 256 KiB read); mode 1: copy `bytes`;
  *      mode 2: read `bytes`, write 5/8 of that (pass 2's read : write mix at N = 8).  dst_dev must hold `bytes`. */
 int svdq_hbm_probe(int32_t mode, const void *src_dev, void *dst_dev, int64_t bytes, void *stream);
 

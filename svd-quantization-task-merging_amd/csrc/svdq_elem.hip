@@ -305,18 +305,20 @@ __device__ __forceinline__ unsigned long long load_mask8(const uint8_t *p, int l
     return w;
 }
 
+// strategy: low byte = SVDQ_MASK_*; for the majority vote bits 8.. hold (votes needed + 1), 0 = the default threshold 0.5
 __device__ __forceinline__ unsigned long long vote8(unsigned long long acc, int n_masks, int strategy) {
     unsigned long long out = 0;
+    const int kind = strategy & 0xff, need1 = strategy >> 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int v = (int)((acc >> (8 * e)) & 0xff);
         int bit;
-        if (strategy == SVDQ_MASK_UNION)
+        if (kind == SVDQ_MASK_UNION)
             bit = v > 0;
-        else if (strategy == SVDQ_MASK_INTERSECTION)
+        else if (kind == SVDQ_MASK_INTERSECTION)
             bit = v == n_masks;
         else
-            bit = 2 * v >= n_masks;  // vote_sum >= 0.5 * len(masks), mask_loader.py:483
+            bit = need1 ? (v >= need1 - 1) : (2 * v >= n_masks);  // vote_sum >= threshold * len(masks), mask_loader.py:483
         out |= (unsigned long long)bit << (8 * e);
     }
     return out;
@@ -505,7 +507,8 @@ extern "C" int svdq_mask_combine(const void *mask_ptrs, int32_t n_masks, int64_t
         svdq_set_error("Empty mask list");  // mask_loader.py:425
         return SVDQ_EINVAL;
     }
-    if (strategy < SVDQ_MASK_UNION || strategy > SVDQ_MASK_MAJORITY) {
+    if ((strategy & 0xff) > SVDQ_MASK_MAJORITY || strategy < 0 ||
+        ((strategy >> 8) != 0 && (strategy & 0xff) != SVDQ_MASK_MAJORITY) || (strategy >> 8) > SVDQ_MAX_TASKS + 2) {
         svdq_set_error("Unknown mask strategy: %d", strategy);  // mask_loader.py:611
         return SVDQ_EINVAL;
     }

@@ -193,7 +193,7 @@ class MaskSet:
         return out
 
 
-def _combine(masks: List[torch.Tensor], strategy: str) -> torch.Tensor:
+def _combine(masks: List[torch.Tensor], strategy: str, votes_needed: Optional[int] = None) -> torch.Tensor:
     if not masks:
         raise ValueError("Empty mask list")
     if strategy not in nat.MASK_STRATEGIES:
@@ -214,7 +214,10 @@ def _combine(masks: List[torch.Tensor], strategy: str) -> torch.Tensor:
     count = torch.zeros(1, dtype=torch.int64, device=dev)
     work = torch.empty(int(lib.svdq_mask_work_bytes(numel)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        nat.check(lib.svdq_mask_combine(_ptr(table), len(flat), numel, nat.MASK_STRATEGIES[strategy], _ptr(out),
+        code = nat.MASK_STRATEGIES[strategy]
+        if votes_needed is not None:
+            code |= (int(votes_needed) + 1) << 8
+        nat.check(lib.svdq_mask_combine(_ptr(table), len(flat), numel, code, _ptr(out),
                                         _ptr(count), _ptr(work), _stream_ptr()), "svdq_mask_combine")
     return out.view(torch.bool).view(shape).to(out_dev)
 
@@ -228,9 +231,18 @@ def compute_intersection_mask(masks: List[torch.Tensor]) -> torch.Tensor:
 
 
 def compute_majority_mask(masks: List[torch.Tensor], threshold: float = 0.5) -> torch.Tensor:
-    if threshold != 0.5:
-        raise ValueError("only the reference's default threshold 0.5 is implemented on the HIP path")
-    return _combine(masks, "majority")
+    """Reference mask_loader.py:456-485: ``vote_sum >= threshold * len(masks)``.  The reference compares an fp32
+    count tensor with the Python product; torch casts that scalar to fp32, so the smallest passing count is
+    ceil(fp32(threshold * n)) -- computed here on the host and handed to the kernel as an integer."""
+    if not masks:
+        raise ValueError("Empty mask list")
+    if threshold == 0.5:
+        return _combine(masks, "majority")
+    import math
+    import numpy as np
+    bound = float(np.float32(threshold * len(masks)))
+    need = max(0, min(len(masks) + 1, int(math.ceil(bound)))) if math.isfinite(bound) else (0 if bound < 0 else len(masks) + 1)
+    return _combine(masks, "majority", votes_needed=need)
 
 
 def combine_masks(task_masks: Dict[str, Dict[str, torch.Tensor]], strategy: str = "union", device: str = "cpu",

@@ -277,6 +277,12 @@ def gen_masks():
     # even-N tie for majority (reference tests/test_mask_strategies.py): >= 0.5 * n
     even = ref_masks.compute_majority_mask(masks[:4])
     out["majority_even4"] = even.numpy()
+    # other thresholds (mask_loader.py:456-485), incl. products that are not exact in fp32 and the two extremes
+    thr_list = [0.0, 0.2, 0.3, 0.4, 0.6, 0.75, 0.8, 1.0, 1.2]
+    out["majority_thresholds"] = np.array(thr_list, dtype=np.float64)
+    for i, thr in enumerate(thr_list):
+        out[f"majority_thr{i}_n5"] = ref_masks.compute_majority_mask(masks, threshold=thr).numpy()
+        out[f"majority_thr{i}_n3"] = ref_masks.compute_majority_mask(masks[:3], threshold=thr).numpy()
     union = torch.from_numpy(out["combined_union"])
     sig = [ref_masks.apply_mask_to_tensor(d, union) for d in deltas]
     noi = [ref_masks.get_unmasked_portion(d, union) for d in deltas]

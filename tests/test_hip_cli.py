@@ -179,3 +179,18 @@ def test_cli_from_checkpoints_route_matches(sq, tmp_path):
     for k in shapes:
         assert torch.equal(a["bases"][k]["masked"]["U_low"], b["bases"][k]["masked"]["U_low"])
     assert a["compression_statistics"]["summary"] == b["compression_statistics"]["summary"]
+
+
+def test_main_dispatcher_runs_svd_hybrid(sq, tmp_path):
+    """reference src/main.py:41-89: `--method svd_hybrid` (also the default) hands the remaining flags to the SVD-Hybrid
+    command line; as a subprocess, like a user would call it."""
+    tasks = ["Cars", "DTD", "EuroSAT", "GTSRB"]
+    base, shapes, deltas = _write_checkpoints(tmp_path, tasks, False)
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "main.py"), "--method", "svd_hybrid", "--tasks", *tasks,
+           "--checkpoint-dir", str(tmp_path / "ckpt"), "--base-model-path", str(tmp_path / "base.pt"),
+           "--energy-threshold", "0.9", "--max-rank", "1", "--output-dir", str(out), "--artifact-dir", str(tmp_path / "art")]
+    rc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert rc.returncode == 0, rc.stdout[-2000:] + rc.stderr[-2000:]
+    merged = torch.load(out / "merged_state_dict.pt", map_location="cpu", weights_only=True)
+    assert set(merged.keys()) == set(base.keys())

@@ -740,6 +740,10 @@ def test_masks_vs_reference_vectors(sq):
         assert comb["w"].dtype == torch.bool
         assert np.array_equal(comb["w"].cpu().numpy(), g[f"combined_{strat}"])
     assert np.array_equal(sq.compute_majority_mask(masks[:4]).cpu().numpy(), g["majority_even4"])
+    for i, thr in enumerate(g["majority_thresholds"]):      # compute_majority_mask(threshold != 0.5)
+        assert np.array_equal(sq.compute_majority_mask(masks, threshold=float(thr)).cpu().numpy(), g[f"majority_thr{i}_n5"]), thr
+        assert np.array_equal(sq.compute_majority_mask(masks[:3], threshold=float(thr)).cpu().numpy(),
+                              g[f"majority_thr{i}_n3"]), thr
     union = torch.from_numpy(g["combined_union"]).cuda()
     deltas = [torch.from_numpy(d).cuda() for d in g["deltas"]]
     sig = torch.stack([sq.apply_mask_to_tensor(d, union) for d in deltas])
