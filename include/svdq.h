@@ -184,6 +184,12 @@ int svdq_compress_gather(const svdq_plan *plan, const void *delta_ptrs, const vo
 int svdq_compress_from_base(const svdq_plan *plan, const void *finetuned_ptrs, const void *base_ptrs,
                             const int64_t *rows_dev, void *workspace_dev, void *small_dev, void *basis_dev,
                             float *mean_dev, void *stream);
+/*      svdq_compress_gather_from_base: both at once -- masked parameters straight from checkpoints (cli.py Step 1 +
+ *      the flat[mask] selections of Steps 4 and 5): finetuned[idx] - base[idx] is formed in registers.  Bit-identical to
+ *      svdq_ingest followed by svdq_compress_gather. */
+int svdq_compress_gather_from_base(const svdq_plan *plan, const void *finetuned_ptrs_dev, const void *base_ptrs_dev,
+                                   const void *index_ptrs_dev, const int64_t *rows_dev, void *workspace, void *small,
+                                   void *basis, float *mean, void *stream);
 
 /* ---- the step before the path: task-vector ingest and whole-tensor quantization ("TVQ"),
  * batched over a plan's parameters x tasks.  All pointer tables are DEVICE arrays of device addresses,

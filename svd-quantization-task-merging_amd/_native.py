@@ -88,6 +88,8 @@ SIGNATURES = {
                                        c_void_p]),
     "svdq_compress_from_base": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p]),
+    "svdq_compress_gather_from_base": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p]),
     "svdq_project": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
     "svdq_project_work_bytes": (c_int64, [c_int64, c_int32]),

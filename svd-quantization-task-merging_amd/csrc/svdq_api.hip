@@ -441,3 +441,26 @@ extern "C" int svdq_compress_from_base(const svdq_plan *pl, const void *finetune
     if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
     return rc;
 }
+
+// Both at once: masked parameters straight from checkpoints.  finetuned_ptrs name the ORIGINAL (full-size) fine-tuned
+// tensors, base_ptrs the base tensors, index_ptrs the selected positions; finetuned[idx] - base[idx] is formed in
+// registers in both passes.  Bit-identical to svdq_ingest followed by svdq_compress_gather.
+extern "C" int svdq_compress_gather_from_base(const svdq_plan *pl, const void *finetuned_ptrs, const void *base_ptrs,
+                                              const void *index_ptrs, const int64_t *rows_dev, void *workspace,
+                                              void *small, void *basis, float *mean, void *stream) {
+    if (!pl || !base_ptrs || !index_ptrs || !rows_dev) {
+        svdq_set_error("svdq_compress_gather_from_base: plan, base_ptrs, index_ptrs and rows_dev are required");
+        return SVDQ_EINVAL;
+    }
+    if (small)
+        HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(small) + pl->small.status_off, 0, sizeof(int32_t),
+                               (hipStream_t)stream));
+    int rc = gram_range(pl, finetuned_ptrs, rows_dev, workspace, 0, pl->n_params, index_ptrs, stream, base_ptrs);
+    if (rc == SVDQ_OK)
+        rc = eig_range(pl, finetuned_ptrs, rows_dev, workspace, small, 0, pl->n_params, index_ptrs, stream, base_ptrs);
+    if (rc == SVDQ_OK)
+        rc = bp_range(pl, finetuned_ptrs, rows_dev, workspace, small, basis, mean, 0, pl->n_params, index_ptrs, stream,
+                      base_ptrs);
+    if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
+    return rc;
+}

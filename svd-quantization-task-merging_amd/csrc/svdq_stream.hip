@@ -156,6 +156,23 @@ __device__ __forceinline__ f32x4 load_base(gfloat *b, int64_t rb, int64_t D, int
     return o;
 }
 
+// base rows of a gathered block (minus-base mode combined with gather mode): same indices as the task rows
+__device__ __forceinline__ f32x4 load_base_gather(gfloat *b, const i32x4 &ix, bool full) {
+    f32x4 o = zero4();
+    if (full) {
+        o.x = b[ix.x];
+        o.y = b[ix.y];
+        o.z = b[ix.z];
+        o.w = b[ix.w];
+    } else {
+        if (ix.x >= 0) o.x = b[ix.x];
+        if (ix.y >= 0) o.y = b[ix.y];
+        if (ix.z >= 0) o.z = b[ix.z];
+        if (ix.w >= 0) o.w = b[ix.w];
+    }
+    return o;
+}
+
 template <int NTP>
 __device__ __forceinline__ void load_block_gather(f32x4 (&v)[NTP], gfloat *(&bp)[NTP], const i32x4 &ix, bool full) {
     if (full) {
@@ -232,8 +249,8 @@ __device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int
 // ------------------------------------------------------------------------------------ pass 1
 // One work unit of pass 1 (a run of 256-row blocks of one parameter) by ONE wavefront.
 // X: NTP*XS floats of wave-private LDS.
-// MODE 0: contiguous task vectors; 1: gather through an index list (aux[p] = int32 list); 2: fine-tuned tensors
-// minus a base tensor (aux[p] = base)
+// MODE bit 0: gather through an index list (aux[p] = int32 list); bit 1: the task tensors are fine-tuned weights and a
+// base tensor is subtracted in registers (aux2[p] = base).  0 = contiguous task vectors, 3 = both.
 // F64: the products are accumulated by v_mfma_f64_16x16x4_f64 (exact fp32 x fp32 products, fp64 running sums over the
 // whole unit), which resolves singular values down to ~1e-6 sigma_0 like the reference's LAPACK path; the fp32 form
 // (fp32 sums inside a 256-row block) only reaches ~1e-3..1e-4 sigma_0.  Pass 1 is HBM-bound for N <= 16, so the fp64
@@ -245,8 +262,9 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
                                           const int64_t *__restrict__ rows_dev, int NT, int center,
                                           double *__restrict__ gram_part,
                                           const void *const *__restrict__ aux = nullptr,
-                                          const int32_t *__restrict__ only = nullptr) {
-    constexpr bool GATHER = (MODE == 1), SUB = (MODE == 2);
+                                          const int32_t *__restrict__ only = nullptr,
+                                          const void *const *__restrict__ aux2 = nullptr) {
+    constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0;
     static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
@@ -295,17 +313,18 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     i32x4 ixn = {-1, -1, -1, -1};  // indices of the block after the one whose data is in flight
     gfloat *gbase = nullptr;
     f32x4 vb = zero4();  // base rows of the block whose fine-tuned rows sit in v
+    if constexpr (SUB) gbase = (gfloat *)aux2[p];
     if constexpr (GATHER) {
         gidx = (gint *)aux[p];
         if (r_begin < r_end) {
             const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
             load_block_gather<NTP>(v0, bp, ix0, r_begin + SVDQ_BLK_ROWS <= D);
+            if constexpr (SUB) vb = load_base_gather(gbase, ix0, r_begin + SVDQ_BLK_ROWS <= D);
             if (r_begin + SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, r_begin + SVDQ_BLK_ROWS, D, lane);
         }
     } else {
         if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
         if constexpr (SUB) {
-            gbase = (gfloat *)aux[p];
             if (r_begin < r_end) vb = load_base(gbase, r_begin, D, lane);
         }
     }
@@ -337,6 +356,7 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
         if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
             if constexpr (GATHER) {
                 load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
+                if constexpr (SUB) vb = load_base_gather(gbase, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
                 if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
             } else {
                 load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
@@ -493,10 +513,11 @@ __global__ __launch_bounds__(64, (F64 && MODE == 0 && NTP <= 16) ? (NTP <= 8 ? S
                                              const int64_t *__restrict__ rows_dev, int NT, int center,
                                              double *__restrict__ gram_part, int unit0,
                                              const void *const *__restrict__ aux,
-                                             const int32_t *__restrict__ only) {
+                                             const int32_t *__restrict__ only,
+                                             const void *const *__restrict__ aux2) {
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
     gram_unit<NTP, MODE, F64>(X, unit0 + (int)blockIdx.x, params, units, ptrs, rows_dev, NT, center, gram_part, aux,
-                              only);
+                              only, aux2);
 }
 
 // ------------------------------------------------------------------------------------ pass 2
@@ -550,8 +571,9 @@ __device__ __forceinline__ void bp_unit(
     const SvdqUnit *__restrict__ units, const float *const *__restrict__ ptrs,
     const int64_t *__restrict__ rows_dev, int NT, int center, const float *__restrict__ Wtab,
     const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev, uint8_t *__restrict__ basis,
-    float *__restrict__ meanbuf, double *__restrict__ cpart, const void *const *__restrict__ aux = nullptr) {
-    constexpr bool GATHER = (MODE == 1), SUB = (MODE == 2);
+    float *__restrict__ meanbuf, double *__restrict__ cpart, const void *const *__restrict__ aux = nullptr,
+    const void *const *__restrict__ aux2 = nullptr) {
+    constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0;
     static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
@@ -637,17 +659,18 @@ __device__ __forceinline__ void bp_unit(
     i32x4 ixn = {-1, -1, -1, -1};  // indices of the block after the one whose data is in flight
     gfloat *gbase = nullptr;
     f32x4 vb = zero4();  // base rows of the block whose fine-tuned rows sit in v
+    if constexpr (SUB) gbase = (gfloat *)aux2[p];
     if constexpr (GATHER) {
         gidx = (gint *)aux[p];
         if (r_begin < r_end) {
             const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
             load_block_gather<NTP>(v0, bp, ix0, r_begin + SVDQ_BLK_ROWS <= D);
+            if constexpr (SUB) vb = load_base_gather(gbase, ix0, r_begin + SVDQ_BLK_ROWS <= D);
             if (r_begin + SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, r_begin + SVDQ_BLK_ROWS, D, lane);
         }
     } else {
         if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
         if constexpr (SUB) {
-            gbase = (gfloat *)aux[p];
             if (r_begin < r_end) vb = load_base(gbase, r_begin, D, lane);
         }
     }
@@ -686,6 +709,7 @@ __device__ __forceinline__ void bp_unit(
         if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
             if constexpr (GATHER) {
                 load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
+                if constexpr (SUB) vb = load_base_gather(gbase, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
                 if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
             } else {
                 load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
@@ -827,13 +851,13 @@ __global__ __launch_bounds__(64) void k_basis_project(
     const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
     const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
     uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse,
-    const void *const *__restrict__ aux) {
+    const void *const *__restrict__ aux, const void *const *__restrict__ aux2) {
     using out_t = typename OutT<OUT16>::type;
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
     __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];  // +16: dump slot for idle lanes
     const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
     bp_unit<NTP, OUT16, MODE>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis,
-                              meanbuf, cpart, aux);
+                              meanbuf, cpart, aux, aux2);
 }
 
 // ------------------------------------------------------------------------------------ N > 16: two waves
@@ -887,7 +911,7 @@ __device__ __forceinline__ f32x4 center_store_half(const f32x4 (&v)[HT], int t0,
 // first block + one-block-ahead loads of one wave's HT tasks (contiguous or through the index list)
 template <int HT, int MODE>
 struct HalfLoader {
-    static constexpr bool GATHER = (MODE == 1), SUB = (MODE == 2);
+    static constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0;
     gfloat *bp[HT];
     gint *gidx;
     gfloat *gbase;
@@ -905,12 +929,13 @@ struct HalfLoader {
         ixn = i32x4{-1, -1, -1, -1};
         vb = zero4();
         if (r_begin >= r_end) return;
-        if constexpr (SUB) vb = load_base(gbase, r_begin, D, lane);
         if constexpr (GATHER) {
             const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
             load_block_gather<HT>(v, bp, ix0, r_begin + SVDQ_BLK_ROWS <= D);
+            if constexpr (SUB) vb = load_base_gather(gbase, ix0, r_begin + SVDQ_BLK_ROWS <= D);
             if (r_begin + SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, r_begin + SVDQ_BLK_ROWS, D, lane);
         } else {
+            if constexpr (SUB) vb = load_base(gbase, r_begin, D, lane);
             load_block<HT>(v, bp, r_begin, D, lane);
         }
     }
@@ -918,6 +943,7 @@ struct HalfLoader {
         if (rb + SVDQ_BLK_ROWS >= r_end) return;
         if constexpr (GATHER) {
             load_block_gather<HT>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
+            if constexpr (SUB) vb = load_base_gather(gbase, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
             if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
         } else {
             load_block<HT>(v, bp, rb + SVDQ_BLK_ROWS, D, lane);
@@ -942,9 +968,9 @@ __global__ __launch_bounds__(128) void k_basis_project2(
     const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
     const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
     uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse,
-    const void *const *__restrict__ aux) {
+    const void *const *__restrict__ aux, const void *const *__restrict__ aux2) {
     static_assert(NTP > 16 && NTP <= 32 && NTP % 4 == 0, "two-wave variant is for 16 < N <= 32");
-    constexpr bool GATHER = (MODE == 1);
+    constexpr bool GATHER = (MODE & 1) != 0;
     using out_t = typename OutT<OUT16>::type;
     constexpr int HT = NTP / 2;
     constexpr int KS = NTP / 4;
@@ -968,7 +994,7 @@ __global__ __launch_bounds__(128) void k_basis_project2(
 #pragma unroll
     for (int i = 0; i < HT; ++i) ld.bp[i] = (gfloat *)ptrs[(size_t)p * NT + (t0 + i < NT ? t0 + i : NT - 1)];
     ld.gidx = GATHER ? (gint *)aux[p] : nullptr;
-    ld.gbase = (MODE == 2) ? (gfloat *)aux[p] : nullptr;
+    ld.gbase = (MODE & 2) ? (gfloat *)aux2[p] : nullptr;
     ld.D = D;
     ld.r_end = r_end;
     ld.lane = lane;
@@ -1101,22 +1127,32 @@ UNROLL_N(SVDQ_UNROLL_BP2)
 }
 
 // ------------------------------------------------------------------------------------ launchers
+// idx: NULL or the device table of index lists (gather mode); base: NULL or the device table of base tensors
+// (minus-base mode); both may be given (masked parameters straight from checkpoints).
 template <int NTP>
 static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
                          int unit0, int nunits, int center, const void *idx, const void *base, int f64,
                          const int32_t *only, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
-#define SVDQ_LAUNCH_GRAM(M, F, AUX)                                                                                  \
+    auto ai = (const void *const *)idx, ab = (const void *const *)base;
+#define SVDQ_LAUNCH_GRAM(M, F)                                                                                       \
     hipLaunchKernelGGL((k_gram<NTP, M, F>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, rows_dev, \
-                       pl->n_tasks, center, gram_part, unit0, (const void *const *)(const void *)(AUX), only)
+                       pl->n_tasks, center, gram_part, unit0, ai, only, ab)
+    const int mode = (idx ? 1 : 0) | (base ? 2 : 0);
     if (f64) {
-        if (idx) SVDQ_LAUNCH_GRAM(1, true, idx);
-        else if (base) SVDQ_LAUNCH_GRAM(2, true, base);
-        else SVDQ_LAUNCH_GRAM(0, true, nullptr);
+        switch (mode) {
+            case 0: SVDQ_LAUNCH_GRAM(0, true); break;
+            case 1: SVDQ_LAUNCH_GRAM(1, true); break;
+            case 2: SVDQ_LAUNCH_GRAM(2, true); break;
+            default: SVDQ_LAUNCH_GRAM(3, true); break;
+        }
     } else {
-        if (idx) SVDQ_LAUNCH_GRAM(1, false, idx);
-        else if (base) SVDQ_LAUNCH_GRAM(2, false, base);
-        else SVDQ_LAUNCH_GRAM(0, false, nullptr);
+        switch (mode) {
+            case 0: SVDQ_LAUNCH_GRAM(0, false); break;
+            case 1: SVDQ_LAUNCH_GRAM(1, false); break;
+            case 2: SVDQ_LAUNCH_GRAM(2, false); break;
+            default: SVDQ_LAUNCH_GRAM(3, false); break;
+        }
     }
 #undef SVDQ_LAUNCH_GRAM
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
@@ -1127,10 +1163,6 @@ static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *r
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
                      int unit0, int nunits, int center, const void *idx, const void *base, int f64,
                      const int32_t *only, hipStream_t st) {
-    if (idx && base) {
-        svdq_set_error("gather mode and minus-base mode cannot be combined");
-        return SVDQ_EUNSUPPORTED;
-    }
 #define SVDQ_GRAM_CASE(n) \
     case n: return launch_gram_t<n>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, f64, only, st)
     switch (pl->ntp) {
@@ -1142,29 +1174,40 @@ int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
     return SVDQ_EUNSUPPORTED;
 }
 
+template <int NTP, bool F16>
+static void launch_bp_mode(const svdq_plan *pl, const float *const *pp, const int64_t *rows_dev, const float *W,
+                           const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
+                           int unit0, int nunits, int reverse, const void *idx, const void *base, hipStream_t st) {
+    auto ai = (const void *const *)idx, ab = (const void *const *)base;
+#define SVDQ_LAUNCH_BP(M)                                                                                             \
+    do {                                                                                                              \
+        if constexpr (NTP > 16)                                                                                       \
+            hipLaunchKernelGGL((k_basis_project2<NTP, F16, M>), dim3(nunits), dim3(128), 0, st, pl->d_params,         \
+                               pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
+                               cpart, unit0, reverse, ai, ab);                                                        \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_basis_project<NTP, F16, M>), dim3(nunits), dim3(64), 0, st, pl->d_params,           \
+                               pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
+                               cpart, unit0, reverse, ai, ab);                                                        \
+    } while (0)
+    switch ((idx ? 1 : 0) | (base ? 2 : 0)) {
+        case 0: SVDQ_LAUNCH_BP(0); break;
+        case 1: SVDQ_LAUNCH_BP(1); break;
+        case 2: SVDQ_LAUNCH_BP(2); break;
+        default: SVDQ_LAUNCH_BP(3); break;
+    }
+#undef SVDQ_LAUNCH_BP
+}
+
 template <int NTP>
 static int launch_bp_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                        const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
                        int unit0, int nunits, int reverse, const void *idx, const void *base, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
-#define SVDQ_LAUNCH_BP(F16, M, AUX)                                                                                   \
-    do {                                                                                                              \
-        auto ax = (const void *const *)(const void *)(AUX);                                                         \
-        if constexpr (NTP > 16)                                                                                       \
-            hipLaunchKernelGGL((k_basis_project2<NTP, F16, M>), dim3(nunits), dim3(128), 0, st, pl->d_params,         \
-                               pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
-                               cpart, unit0, reverse, ax);                                                            \
-        else                                                                                                          \
-            hipLaunchKernelGGL((k_basis_project<NTP, F16, M>), dim3(nunits), dim3(64), 0, st, pl->d_params,           \
-                               pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
-                               cpart, unit0, reverse, ax);                                                            \
-    } while (0)
-    if (pl->cfg.fp16) {
-        if (idx) SVDQ_LAUNCH_BP(true, 1, idx); else if (base) SVDQ_LAUNCH_BP(true, 2, base); else SVDQ_LAUNCH_BP(true, 0, nullptr);
-    } else {
-        if (idx) SVDQ_LAUNCH_BP(false, 1, idx); else if (base) SVDQ_LAUNCH_BP(false, 2, base); else SVDQ_LAUNCH_BP(false, 0, nullptr);
-    }
-#undef SVDQ_LAUNCH_BP
+    if (pl->cfg.fp16)
+        launch_bp_mode<NTP, true>(pl, pp, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+    else
+        launch_bp_mode<NTP, false>(pl, pp, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
@@ -1172,20 +1215,13 @@ int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
                               double *cpart, int unit0, int nunits, int reverse, const void *idx, const void *base,
                               hipStream_t st) {
-    if (idx && base) {
-        svdq_set_error("gather mode and minus-base mode cannot be combined");
-        return SVDQ_EUNSUPPORTED;
-    }
+#define SVDQ_BP_CASE(n) \
+    case n: return launch_bp_t<n>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st)
     switch (pl->ntp) {
-        case 4: return launch_bp_t<4>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
-        case 8: return launch_bp_t<8>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
-        case 12: return launch_bp_t<12>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
-        case 16: return launch_bp_t<16>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
-        case 20: return launch_bp_t<20>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
-        case 24: return launch_bp_t<24>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
-        case 28: return launch_bp_t<28>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
-        case 32: return launch_bp_t<32>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+        SVDQ_BP_CASE(4); SVDQ_BP_CASE(8); SVDQ_BP_CASE(12); SVDQ_BP_CASE(16);
+        SVDQ_BP_CASE(20); SVDQ_BP_CASE(24); SVDQ_BP_CASE(28); SVDQ_BP_CASE(32);
     }
+#undef SVDQ_BP_CASE
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;
 }

@@ -32,9 +32,6 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
     coefficients of Step 5 attached for ``compress_all_parameters``."""
     dev = resolve_device(device)
     combined_masks = combined_masks or {}
-    if base_state is not None and combined_masks:
-        raise ValueError("compressing straight from checkpoints (base_state) does not combine with masks; "
-                         "materialise the task vectors (load_task_vectors) for a masked run")
     names = sorted({n for tv in task_vectors.values() for n in tv.keys()})
     if base_state is not None:   # compute_task_vector's eligibility (task_vector_loader.py:126-139)
         names = [n for n in names if n in base_state and base_state[n].is_floating_point()]
@@ -77,13 +74,14 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
             keep.append((ms, it_, if_))
             for q, (name, present, deltas, _) in enumerate(items):
                 vs = [prepare_vector(d, dev) for d in deltas]
+                bvec = prepare_vector(base_state[name], dev) if base_state is not None else None
                 groups.setdefault((n_present, True), []).append(
                     {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": ct[q:q + 1],
-                     "upper": vs[0].numel(), "min": min_size, "index": it_[q]})
+                     "upper": vs[0].numel(), "min": min_size, "index": it_[q], "base": bvec})
                 if include_noise:
                     groups.setdefault((n_present, True), []).append(
                         {"name": name, "region": "noise", "tasks": present, "vectors": vs, "count": cf[q:q + 1],
-                         "upper": vs[0].numel(), "min": 1, "gate": ct[q:q + 1], "index": if_[q]})
+                         "upper": vs[0].numel(), "min": 1, "gate": ct[q:q + 1], "index": if_[q], "base": bvec})
         order = {n: i for i, n in enumerate(names)}
         for lst in groups.values():
             lst.sort(key=lambda e: (order[e["name"]], e["region"] != "masked"))
@@ -114,7 +112,12 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
                         parts.append(torch.where(ok, c, torch.zeros_like(c)))
                 rows_dev = torch.cat(parts)
             table = plan.pointer_table([e["vectors"] for e in entries])
-            if gather:
+            if gather and base_state is not None:
+                itab = torch.tensor([e["index"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
+                btab = torch.tensor([e["base"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
+                keep.append([e["base"] for e in entries])
+                plan.run_gather_from_base(table, btab, itab, rows_dev)
+            elif gather:
                 itab = torch.tensor([e["index"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
                 plan.run_gather(table, itab, rows_dev)
             elif base_state is not None:
@@ -226,10 +229,12 @@ def run_basis_and_compress(task_vectors, combined_masks, config, device="cuda") 
 
 def run_basis_and_compress_from_checkpoints(base_state: Dict[str, torch.Tensor],
                                             finetuned_states: Dict[str, Dict[str, torch.Tensor]], config,
-                                            device="cuda") -> Tuple[Dict, Dict]:
+                                            device="cuda", combined_masks: Optional[Dict[str, torch.Tensor]] = None
+                                            ) -> Tuple[Dict, Dict]:
     """cli.py Step 1 + Step 4 + Step 5 without materialising the task vectors: ``finetuned - base`` is formed
-    inside the two streaming passes (svdq_compress_from_base).  Same (bases, compressed_all) as
-    load_task_vectors + run_basis_and_compress, bit for bit; unmasked runs only."""
+    inside the two streaming passes (svdq_compress_from_base; with ``combined_masks`` the masked parameters go
+    through svdq_compress_gather_from_base).  Same (bases, compressed_all) as load_task_vectors +
+    run_basis_and_compress, bit for bit."""
     from .compress import compress_all_parameters
-    bases = build_bases(finetuned_states, None, config, device, base_state=base_state)
-    return bases, compress_all_parameters(finetuned_states, {}, bases, config, device)
+    bases = build_bases(finetuned_states, combined_masks, config, device, base_state=base_state)
+    return bases, compress_all_parameters(finetuned_states, combined_masks or {}, bases, config, device)

@@ -118,21 +118,29 @@ class CompressPlan:
         self.workspace = torch.empty(self.sizes.workspace_bytes, dtype=torch.uint8, device=dev)
         self.small = torch.zeros(self.sizes.small_bytes, dtype=torch.uint8, device=dev)
         # gram_only: a plan used for svdq_task_gram alone needs no basis / mean storage
-        self.basis = None if gram_only else torch.empty(self.sizes.basis_bytes, dtype=torch.uint8, device=dev)
-        self.mean = (torch.empty(self.sizes.mean_floats, dtype=torch.float32, device=dev)
-                     if center and not gram_only else None)
+        self.basis, self.mean = (None, None) if gram_only else self._alloc_outputs()
         self._keep = None
 
     # ---- lifetime
+    def _alloc_outputs(self):
+        """Basis and mean in ONE allocation (mean right behind the basis, 256-byte aligned).  Pass 2 writes three
+        streams (U_high, U_low, mean); with the mean in an allocation of its own its time sat on one of two levels
+        from process to process (2.74 / 3.0 ms at ViT-L-14 x 8), with one allocation the slow level is 2.86 ms
+        (tools/placement_probe2.py: mean 2.92 -> 2.81 ms over six candidates each)."""
+        bb = int(self.sizes.basis_bytes)
+        gap = (bb + 255) // 256 * 256
+        nm = int(self.sizes.mean_floats) * 4 if self.center else 0
+        out = torch.empty(gap + nm, dtype=torch.uint8, device=self.device)
+        basis = out[:bb]
+        mean = out[gap:gap + nm].view(torch.float32) if self.center else None
+        return basis, mean
+
     def fresh_outputs(self):
         """New output buffers (small, basis, mean) for the next run; the previous ones stay with whoever holds them.
         The plan's tables and workspace are reused (runs are ordered on the stream they are enqueued on)."""
-        dev = self.device
-        self.small = torch.zeros(self.sizes.small_bytes, dtype=torch.uint8, device=dev)
+        self.small = torch.zeros(self.sizes.small_bytes, dtype=torch.uint8, device=self.device)
         if self.basis is not None:
-            self.basis = torch.empty(self.sizes.basis_bytes, dtype=torch.uint8, device=dev)
-        if self.mean is not None:
-            self.mean = torch.empty(self.sizes.mean_floats, dtype=torch.float32, device=dev)
+            self.basis, self.mean = self._alloc_outputs()
         self._typed = None
 
     def bits_of(self, p: int) -> int:
@@ -235,6 +243,14 @@ class CompressPlan:
                                                    _ptr(self.workspace), _ptr(self.small), _ptr(self.basis),
                                                    _ptr(self.mean), _stream_ptr()), "svdq_compress_from_base")
 
+    def run_gather_from_base(self, finetuned_table, base_table, index_table, rows_dev):
+        """run_gather() straight from checkpoints: the tables name the full-size fine-tuned and base tensors,
+        ``index_table`` the selected positions; finetuned[idx] - base[idx] is formed inside the streaming passes."""
+        nat.check(self.lib.svdq_compress_gather_from_base(self._h, _ptr(finetuned_table), _ptr(base_table),
+                                                          _ptr(index_table), _ptr(rows_dev), _ptr(self.workspace),
+                                                          _ptr(self.small), _ptr(self.basis), _ptr(self.mean),
+                                                          _stream_ptr()), "svdq_compress_gather_from_base")
+
     def tune_placement(self, table, rows_dev=None, candidates: int = 4, reps: int = 3) -> List[float]:
         """Pick the output allocation pass 2 runs fastest into.
 
@@ -250,11 +266,11 @@ class CompressPlan:
         with torch.cuda.device(dev):
             self.gram_center(table, rows_dev)          # pass 2 needs W, k, r of these inputs
             self.eig_rank_select(table, rows_dev)
-            pool = [self.basis] + [torch.empty(self.sizes.basis_bytes, dtype=torch.uint8, device=dev)
-                                   for _ in range(candidates - 1)]
+            pool = [(self.basis, self.mean)] + [self._alloc_outputs() for _ in range(candidates - 1)]
             times = []
-            for buf in pool:
-                self.basis = buf
+            for buf, mbuf in pool:
+                self.basis, self.mean = buf, mbuf
+                self._typed = None
                 self.basis_project(table, rows_dev)    # warm-up into this buffer
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -264,7 +280,8 @@ class CompressPlan:
                 e1.synchronize()
                 times.append(e0.elapsed_time(e1) / reps)
             best = min(range(len(pool)), key=lambda i: times[i])
-            self.basis = pool[best]
+            self.basis, self.mean = pool[best]
+            self._typed = None
             self.basis_project(table, rows_dev)
             self.coeff_quantize()
             torch.cuda.current_stream().synchronize()
@@ -298,15 +315,17 @@ class CompressPlan:
         hi_bytes = rows * k * es
         lo_off = base + (hi_bytes + 255) // 256 * 256
         nl = r - k
-        # one as_strided per view (slab offsets are 256-byte aligned, so they are whole elements)
-        U_high = torch.as_strided(typed, (rows, k), (k, 1), base // es)
+        # one as_strided per view (slab offsets are 256-byte aligned, so they are whole elements); as_strided takes
+        # offsets into the STORAGE, and basis / mean are themselves views into one allocation
+        t0 = typed.storage_offset()
+        U_high = torch.as_strided(typed, (rows, k), (k, 1), t0 + base // es)
         if nl > 0:
-            U_low = torch.as_strided(typed, (rows, nl), (nl, 1), lo_off // es)
+            U_low = torch.as_strided(typed, (rows, nl), (nl, 1), t0 + lo_off // es)
         else:
             U_low = torch.empty((rows, 0), dtype=typed.dtype, device=self.device)
         mean = None
         if self.center:
-            mean = torch.as_strided(self.mean, (rows, 1), (1, 1), self.mean_off[p])
+            mean = torch.as_strided(self.mean, (rows, 1), (1, 1), self.mean.storage_offset() + self.mean_off[p])
         return U_high, U_low, mean
 
     def _typed_basis(self) -> torch.Tensor:

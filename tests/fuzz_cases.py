@@ -2,8 +2,8 @@
 
 oracle_case : random (D, N, thresholds, centre, fp16, bits, stages) against the CPU oracle (the restated reference op
               sequence): singular values, rank, retained energy, reconstructions.
-modes_case  : gather mode (against compacted copies) and minus-base mode (against ingest + compress) must reproduce
-              the plain path bit for bit.
+modes_case  : gather mode (against compacted copies), minus-base mode (against ingest + compress) and both combined
+              (against ingest + gather) must reproduce the plain path bit for bit.
 Each returns a (description, [mismatch messages]) pair; an empty list means the case is within tolerance."""
 import random
 
@@ -129,6 +129,18 @@ def modes_case(sq, dev, seed: int, c: int):
     m = _same(r3, ga)
     if m:
         msgs.append("gather: " + m)
-    for pl in (r2, fb, r3, ga):
+    # both at once: gather through the index lists straight from fine-tuned + base tensors vs ingest + gather
+    r4 = CompressPlan(sizes, N, **kw)
+    ingv = [ing[p * N:(p + 1) * N] for p in range(P)]
+    itab = torch.tensor([x.data_ptr() for x in it], dtype=torch.int64).to(dev)
+    r4.run_gather(r4.pointer_table(ingv), itab, ct2)
+    gb = CompressPlan(sizes, N, **kw)
+    gb.run_gather_from_base(gb.pointer_table(fts), torch.tensor([b.data_ptr() for b in base], dtype=torch.int64).to(dev),
+                            itab, ct2)
+    torch.cuda.synchronize()
+    m = _same(r4, gb)
+    if m:
+        msgs.append("gather_from_base: " + m)
+    for pl in (r2, fb, r3, ga, r4, gb):
         pl.close()
     return desc, msgs

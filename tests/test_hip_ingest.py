@@ -229,5 +229,24 @@ def test_run_from_checkpoints_matches_task_vector_route(sq, g):
             for p1, p2 in zip(a1["c_low_quant"]["payloads"], a2["c_low_quant"]["payloads"]):
                 assert torch.equal(p1["quantized"], p2["quantized"])
                 assert bits_equal(p1["scale"].numpy(), p2["scale"].numpy())      # NaN == NaN (F4: one-element c_low)
-    with pytest.raises(ValueError, match="does not combine with masks"):
-        sq.build_bases(fts, {"w1": torch.ones(40, 30, dtype=torch.bool)}, cfg, "cuda", base_state=base)
+    # masked parameters straight from checkpoints (gather + minus-base in one pass): same as the task-vector route
+    gm = torch.Generator().manual_seed(3)
+    masks = {"w1": torch.rand(tv[next(iter(tv))]["w1"].shape, generator=gm) > 0.4}
+    cfgn = sq.SVDHybridConfig(svd_energy_threshold=0.9, svd_max_rank=2, svd_include_noise=True)
+    bases3, comp3 = sq.run_basis_and_compress(tv, masks, cfgn, "cuda")
+    bases4, comp4 = sq.run_basis_and_compress_from_checkpoints(base, fts, cfgn, "cuda", combined_masks=masks)
+    assert sorted(bases3) == sorted(bases4)
+    for name in bases3:
+        for region, akey in (("masked", "masked"), ("noise", "unmasked")):
+            b3, b4 = bases3[name][region], bases4[name][region]
+            assert (b3 is None) == (b4 is None)
+            if b3 is None:
+                continue
+            assert b3["k"] == b4["k"] and b3["D"] == b4["D"]
+            assert torch.equal(b3["U_high"], b4["U_high"]) and torch.equal(b3["U_low"], b4["U_low"])
+            for t in comp3[name]:
+                a3, a4 = comp3[name][t][akey], comp4[name][t][akey]
+                assert torch.equal(a3["c_high_fp16"], a4["c_high_fp16"])
+                for p3, p4 in zip(a3["c_low_quant"]["payloads"], a4["c_low_quant"]["payloads"]):
+                    assert torch.equal(p3["quantized"], p4["quantized"])
+    assert bases3["w1"]["noise"] is not None and bases3["w1"]["masked"]["D"] == int(masks["w1"].sum())
