@@ -75,6 +75,8 @@ def parse():
                          "driver.run_basis_and_compress delivers")
     ap.add_argument("--gram32", action="store_true",
                     help="A/B: fp32-product Gram in pass 1 (the round-1 kernel) instead of the fp64-MFMA Gram")
+    ap.add_argument("--bp2", action="store_true",
+                    help="A/B, N = 17..20: the two-wave pass 2 (round 1) instead of the one-wave 4x4-block kernel")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -216,7 +218,7 @@ class Workload:
         self.args, self.rows, self.dev, self.world, self.on_cpu = args, rows, dev, world, on_cpu
         N = args.tasks
         self.bufs, self.views = workloads.synth_task_buffers(rows, N, seed=seed, device=dev)
-        flags = 2 if args.gram32 else 0
+        flags = (2 if args.gram32 else 0) | (8 if args.bp2 else 0)
         self.plan = plan = CompressPlan(rows, N, energy_threshold=args.energy, max_rank=64, center=True, fp16=True,
                                         low_bits=args.bits, rtvq_stages=args.stages, device=dev,
                                         unit_rows=args.unit_rows, flags=flags)

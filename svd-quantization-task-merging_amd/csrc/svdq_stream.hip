@@ -1126,6 +1126,352 @@ UNROLL_N(SVDQ_UNROLL_BP2)
         }
 }
 
+// ------------------------------------------------------------------------------------ 16 < N <= 24: one wave, 4x4 blocks
+// At N = 17..20 the two-wave kernel above pays for 32 column slots where 20 are real: its second wave runs a full
+// 16-column MFMA tile, and above all the full fp16 staging / rounding-error arithmetic, for 4 columns -- and that
+// vector work, not memory, sets its time (4.4 TB/s at N = 20; 910 vector instructions per block and wave = 1 820 per
+// 256 rows).  This variant has no idle column slots (1 500 vector instructions per 256 rows; ViT-L-14 x 20: pass 2
+// 8.66 -> 8.0 ms, 4.35 -> 4.7 TB/s.  At N = 21..24, eight 4x4-block columns, it is slower than the two-wave kernel,
+// which stays in charge there):
+//   * one wavefront per workgroup on HALF blocks of 128 rows (lane = 2 rows per task: the 40 prefetch registers of
+//     the two-wave kernel without its barriers and row-sum exchange);
+//   * columns 0..15: v_mfma_f32_16x16x4_f32 per 16-row sub-tile as before;
+//   * columns 16..: v_mfma_f32_4x4x1_16b_f32 -- sixteen independent 4x4 blocks, block b = rows 4b..4b+3 of a 64-row
+//     group, A = the strip value of ONE task for those rows (lane l reads X[task][64 grp + l]), B = W[task][16 + 4q + j],
+//     one instruction per task: 64 rows x 4 columns per chain, every result register a real output
+//     (lane (b, j) register i = U[row 4b + i][col 16 + 4q + j]), 8 cycles per instruction;
+//   * their rounding correction E^T Tc with v_mfma_f32_4x4x4_16b_bf16: B = the lane's own four errors (rows 4b..4b+3
+//     of its column), A = four rows of four tasks from the strip; block partial sums meet in a shuffle at the end.
+// Layouts of the two small-block MFMAs were determined on the device (tools/probe/mfma_layout.hip): lane l belongs to
+// block l / 4, supplies A[i = l % 4] and B[j = l % 4], and holds D[i = register][j = l % 4].
+// The fp32 dot products run over the tasks in the same order as in the 16x16x4 chain (one fused multiply-add each).
+#define SVDQ_HB 128    // rows per half block
+#ifndef SVDQ_XSH
+#define SVDQ_XSH 144   // LDS row stride (floats) of one task's 128-row strip: 128 + 16 (the four task rows a 16x16x4
+                       // operand read touches land in different banks: 8.08 -> 8.00 ms at N = 20 against 132)
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) f32x2 gf32x2;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ s16x4 pack_bf16x4(const f32x4 &x) {
+    union { __bf16 h[4]; s16x4 v; } u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u.h[e] = (__bf16)x[e];
+    return u.v;
+}
+
+#ifndef SVDQ_Q_WAVES
+#define SVDQ_Q_WAVES 1
+#endif
+template <int NTP, bool OUT16, int MODE>
+__global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
+    const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
+    const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
+    const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
+    uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse,
+    const void *const *__restrict__ aux, const void *const *__restrict__ aux2) {
+    static_assert(NTP == 20 || NTP == 24, "the 4x4-block variant covers 16 < N <= 24");
+    constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0;
+    using out_t = typename OutT<OUT16>::type;
+    constexpr int KS = NTP / 4;    // k-steps of the 16x16x4 chain = task groups of the 4x4x4 correction
+    constexpr int N1 = NTP - 16;   // columns handled by the 4x4 blocks
+    constexpr int G1 = N1 / 4;     // groups of four such columns
+    constexpr int ES = OUT16 ? 2 : 4;
+    constexpr int HB = SVDQ_HB, XH = SVDQ_XSH;
+    __shared__ __attribute__((aligned(16))) float X[(NTP + 1) * XH];   // + one row of zeros (task slots past NTP)
+    __shared__ __attribute__((aligned(16))) out_t OUT[HB * NTP + 16];
+    __shared__ float W1[NTP * N1];   // W[task][16 + q]: B operands of the 4x4x1 chain
+
+    const int lane = threadIdx.x & 63;
+    const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    const SvdqUnit ud = units[uidx];
+    const int p = ud.param;
+    const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
+    const int64_t r_begin = ud.row0;
+    int64_t r_end = r_begin + ud.nrows;
+    if (r_end > D) r_end = D;
+    const int k = k_dev[p], r = r_dev[p], nl = r - k;
+
+    // Twenty 64-bit task pointers held across the loop would push the kernel over its scalar-register budget (the
+    // compiler then parks them in vector-register lanes and pays a v_readlane pair per use): they are re-read from the
+    // table for every half block instead (scalar loads, cached), and lanes address with a 32-bit offset from the
+    // unit's first row.
+#ifndef SVDQ_Q_PTR_RELOAD
+#define SVDQ_Q_PTR_RELOAD 0   // measured: the scalar loads in front of every half block cost more than the readlanes
+#endif
+    const float *const *ptab = ptrs + (size_t)p * NT;
+    gfloat *bp[NTP];
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) bp[t] = (gfloat *)ptab[t < NT ? t : NT - 1];
+    gint *gidx = GATHER ? (gint *)aux[p] : nullptr;
+    gfloat *gbase = SUB ? (gfloat *)aux2[p] : nullptr;
+
+    const int c = lane & 15, g = lane >> 4;     // 16x16 tile coordinates
+    const int b4 = lane >> 2, j4 = lane & 3;    // 4x4 block, column inside the block
+    const float *Wp = Wtab + (size_t)p * (NT * NT + 4);
+    const float spike = Wp[NT * NT];
+    const int nullcol = (int)Wp[NT * NT + 1];
+    float w0[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int t = 4 * s + g;
+        w0[s] = (t < NT && c < NT) ? Wp[t * NT + c] : 0.f;
+    }
+    for (int e = lane; e < NTP * N1; e += 64) {
+        const int t = e / N1, q = e % N1;
+        W1[e] = (t < NT && 16 + q < NT) ? Wp[t * NT + 16 + q] : 0.f;
+    }
+    for (int e = lane; e < XH; e += 64) X[NTP * XH + e] = 0.f;
+    // projection B operand ("task on slot, rows on k") of the two 16-task blocks: task 16 nb + c, or the zero row
+    const float *xbrow[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) xbrow[nb] = X + (16 * nb + c < NTP ? 16 * nb + c : NTP) * XH + 4 * g;
+    // staging: every lane owns one column of the 16-column tile and one column of each 4-column group
+    out_t *const OUTh = OUT;
+    out_t *const OUTl = OUT + HB * k;
+    out_t *const DUMP = OUT + HB * NTP;
+    auto col_base = [&](int i) -> out_t * { return i >= r ? DUMP : (i < k ? OUTh + i : OUTl + (i - k)); };
+    auto col_stride = [&](int i) -> int { return i >= r ? 0 : (i < k ? k : nl); };
+    out_t *const cb0 = col_base(c);
+    const int cs0 = col_stride(c);
+    out_t *cb1[G1];
+    int cs1[G1];
+#pragma unroll
+    for (int q = 0; q < G1; ++q) {
+        cb1[q] = col_base(16 + 4 * q + j4);
+        cs1[q] = col_stride(16 + 4 * q + j4);
+    }
+    uint8_t *slab = basis + params[p].slab_off;
+    uint8_t *gUh = slab;
+    uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
+    float *gmean = (center && meanbuf) ? meanbuf + params[p].mean_off : nullptr;
+
+    double caccd[2][4];          // columns 0..15 x tasks (two 16-task blocks): fp32 inside a half block, fp64 across
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) caccd[i][e] = 0.0;
+    f32x4 cacc1[G1][KS];         // columns 16..: [task 4 tg + i][col 16 + 4q + j4], per 4-row block, over the unit
+#pragma unroll
+    for (int q = 0; q < G1; ++q)
+#pragma unroll
+        for (int tg = 0; tg < KS; ++tg) cacc1[q][tg] = zero4();
+
+    // loads of one half block: lane owns rows 2 lane, 2 lane + 1 (gather mode: rows lane, 64 + lane)
+    f32x2 v[NTP];
+    f32x2 vb = {0.f, 0.f};
+    int ixa = -1, ixb = -1;      // gather mode: source positions of the NEXT half block's two rows
+    auto load_idx2 = [&](int64_t rb) {
+        const int64_t ra = rb + lane, rc = rb + 64 + lane;
+        ixa = ra < D ? gidx[ra] : -1;
+        ixb = rc < D ? gidx[rc] : -1;
+    };
+    auto load_half = [&](int64_t rb) {
+        // (the index depends on rb only formally: it keeps the pointer loads inside the loop)
+        const int hop = (int)(rb >> 62);
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) {
+                gfloat *bt = SVDQ_Q_PTR_RELOAD ? (gfloat *)ptab[(t < NT ? t : NT - 1) + hop] : bp[t];
+                f32x2 o = {0.f, 0.f};
+                if (ixa >= 0) o.x = bt[ixa];
+                if (ixb >= 0) o.y = bt[ixb];
+                v[t] = o;
+            }
+            if constexpr (SUB) {
+                vb = f32x2{0.f, 0.f};
+                if (ixa >= 0) vb.x = gbase[ixa];
+                if (ixb >= 0) vb.y = gbase[ixb];
+            }
+        } else {
+            const int64_t rr = rb + 2 * lane;
+            const uint32_t off = (uint32_t)(rb - r_begin) + 2u * (uint32_t)lane;   // rows past the unit's first row
+            if (rb + HB <= D) {
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) {
+                    gfloat *bt = (SVDQ_Q_PTR_RELOAD ? (gfloat *)ptab[(t < NT ? t : NT - 1) + hop] : bp[t]) + r_begin;
+                    v[t] = *reinterpret_cast<gf32x2 *>(bt + off);
+                }
+                if constexpr (SUB) vb = *reinterpret_cast<gf32x2 *>(gbase + rr);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) {
+                    gfloat *bt = SVDQ_Q_PTR_RELOAD ? (gfloat *)ptab[(t < NT ? t : NT - 1) + hop] : bp[t];
+                    f32x2 o = {0.f, 0.f};
+                    if (rr < D) o.x = bt[rr];
+                    if (rr + 1 < D) o.y = bt[rr + 1];
+                    v[t] = o;
+                }
+                if constexpr (SUB) {
+                    vb = f32x2{0.f, 0.f};
+                    if (rr < D) vb.x = gbase[rr];
+                    if (rr + 1 < D) vb.y = gbase[rr + 1];
+                }
+            }
+        }
+    };
+    if (r_begin < r_end) {
+        if constexpr (GATHER) load_idx2(r_begin);
+        load_half(r_begin);
+        if constexpr (GATHER) {
+            if (r_begin + HB < r_end) load_idx2(r_begin + HB);
+        }
+    }
+    wave_sync();   // W1 is in LDS
+
+    for (int64_t rb = r_begin; rb < r_end; rb += HB) {
+        // ---- centre (same association as pass 1 at N > 16: two halves of the tasks), park the strip, write the mean
+        if constexpr (SUB) {
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) v[t] = v[t] - vb;
+        }
+        f32x2 h0 = {0.f, 0.f}, h1 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NTP / 2; ++i) {
+            h0 += (i < NT) ? v[i] : f32x2{0.f, 0.f};
+            h1 += (NTP / 2 + i < NT) ? v[NTP / 2 + i] : f32x2{0.f, 0.f};
+        }
+        const f32x2 tot = h0 + h1;
+        f32x2 mean = {0.f, 0.f};
+        if (center) {
+            const float n = (float)NT;
+            mean.x = tot.x / n;
+            mean.y = tot.y / n;
+        }
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+            const f32x2 xc = (t < NT) ? (v[t] - mean) : f32x2{0.f, 0.f};
+            if constexpr (GATHER) {
+                X[t * XH + lane] = xc.x;
+                X[t * XH + 64 + lane] = xc.y;
+            } else {
+                *reinterpret_cast<f32x2 *>(X + t * XH + 2 * lane) = xc;
+            }
+        }
+        if (gmean) {
+            if constexpr (GATHER) {
+                if (rb + lane < D) gmean[rb + lane] = mean.x;
+                if (rb + 64 + lane < D) gmean[rb + 64 + lane] = mean.y;
+            } else {
+                const int64_t rr = rb + 2 * lane;
+                if (rr + 1 < D) *reinterpret_cast<f32x2 *>(gmean + rr) = mean;
+                else if (rr < D) gmean[rr] = mean.x;
+            }
+        }
+        wave_sync();
+        if (rb + HB < r_end) {   // next half block in flight while this one is computed
+            load_half(rb + HB);
+            if constexpr (GATHER) {
+                if (rb + 2 * HB < r_end) load_idx2(rb + 2 * HB);
+            }
+        }
+
+        // ---- columns 0..15: eight 16-row sub-tiles
+        f32x4 cf[2];
+        cf[0] = zero4();
+        cf[1] = zero4();
+#pragma unroll
+        for (int jj = 0; jj < HB / 32; ++jj) {
+            f32x4 err[2];
+            f32x4 xb[2][2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int j = 2 * jj + s2;
+                f32x4 u = zero4();
+#pragma unroll
+                for (int s = 0; s < KS; ++s) u = mfma4(X[(4 * s + g) * XH + 16 * j + c], w0[s], u);
+                if (j == 0 && rb == 0 && g == 0 && c == nullcol) u[0] += spike;   // completion column, row 0
+                out_t *dst = cb0 + (16 * j + 4 * g) * cs0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (OUT16) {
+                        const __half hh = __float2half_rn(u[e]);
+                        dst[e * cs0] = hh;
+                        err[s2][e] = __half2float(hh) - u[e];
+                    } else {
+                        dst[e * cs0] = u[e];
+                    }
+                }
+                if constexpr (OUT16) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) xb[nb][s2] = *reinterpret_cast<const f32x4 *>(xbrow[nb] + 16 * j);
+                }
+            }
+            if constexpr (OUT16) {
+                const bf16x8 ea = pack_bf16(err[0], err[1]);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) cf[nb] = mfma_bf16(ea, pack_bf16(xb[nb][0], xb[nb][1]), cf[nb]);
+            }
+        }
+        // ---- columns 16..: two 64-row groups of sixteen 4x4 blocks
+#pragma unroll
+        for (int grp = 0; grp < HB / 64; ++grp) {
+#pragma unroll
+            for (int q = 0; q < G1; ++q) {
+                f32x4 u = zero4();
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) u = mfma_4x4x1(X[t * XH + 64 * grp + lane], W1[t * N1 + 4 * q + j4], u);
+                if (grp == 0 && rb == 0 && b4 == 0 && 16 + 4 * q + j4 == nullcol) u[0] += spike;
+                out_t *dst = cb1[q] + (64 * grp + 4 * b4) * cs1[q];
+                f32x4 er;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (OUT16) {
+                        const __half hh = __float2half_rn(u[i]);
+                        dst[i * cs1[q]] = hh;
+                        er[i] = __half2float(hh) - u[i];
+                    } else {
+                        dst[i * cs1[q]] = u[i];
+                    }
+                }
+                if constexpr (OUT16) {
+                    const s16x4 eb = pack_bf16x4(er);
+#pragma unroll
+                    for (int tg = 0; tg < KS; ++tg) {
+                        const f32x4 xa = *reinterpret_cast<const f32x4 *>(X + (4 * tg + j4) * XH + 64 * grp + 4 * b4);
+                        cacc1[q][tg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(pack_bf16x4(xa), eb, cacc1[q][tg], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) caccd[i][e] += (double)cf[i][e];
+        wave_sync();
+        const int rows_blk = (int)((D - rb < HB) ? (D - rb) : HB);
+        if (k > 0) copy_out(OUTh, gUh + rb * (int64_t)k * ES, rows_blk * k * ES, lane);
+        if (nl > 0) copy_out(OUTl, gUl + rb * (int64_t)nl * ES, rows_blk * nl * ES, lane);
+        wave_sync();
+    }
+
+    // rounding-correction partials: cpart[unit][t * NT + i] = sum over rows of E[row][i] * Xc[t][row]
+    double *dst = cpart + (size_t)uidx * NT * NT;
+#pragma unroll
+    for (int nbt = 0; nbt < 2; ++nbt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // lane (c, g) holds D[m = column 4g + e][n = task 16 nbt + c]
+            const int i = 4 * g + e, t = 16 * nbt + c;
+            if (i < NT && t < NT) dst[t * NT + i] = caccd[nbt][e];
+        }
+#pragma unroll
+    for (int q = 0; q < G1; ++q)
+#pragma unroll
+        for (int tg = 0; tg < KS; ++tg)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // lane (b, j) register i holds [task 4 tg + i][col 16 + 4q + j] of block b
+                double x = (double)cacc1[q][tg][i];
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) x += __shfl_xor(x, off);
+                const int t = 4 * tg + i, col = 16 + 4 * q + j4;
+                if (b4 == 0 && t < NT && col < NT) dst[t * NT + col] = x;
+            }
+}
+
 // ------------------------------------------------------------------------------------ launchers
 // idx: NULL or the device table of index lists (gather mode); base: NULL or the device table of base tensors
 // (minus-base mode); both may be given (masked parameters straight from checkpoints).
@@ -1181,6 +1527,14 @@ static void launch_bp_mode(const svdq_plan *pl, const float *const *pp, const in
     auto ai = (const void *const *)idx, ab = (const void *const *)base;
 #define SVDQ_LAUNCH_BP(M)                                                                                             \
     do {                                                                                                              \
+        if constexpr (NTP == 20) {   /* N = 21..24: measured slower than the two-wave kernel (11.9 against 10.0 ms) */ \
+            if (!(pl->cfg.reserved & 8)) {   /* bit 3: the two-wave kernel instead (A/B) */                           \
+                hipLaunchKernelGGL((k_basis_project_q<NTP, F16, M>), dim3(nunits), dim3(64), 0, st, pl->d_params,     \
+                                   pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis,    \
+                                   mean, cpart, unit0, reverse, ai, ab);                                              \
+                break;                                                                                                \
+            }                                                                                                         \
+        }                                                                                                             \
         if constexpr (NTP > 16)                                                                                       \
             hipLaunchKernelGGL((k_basis_project2<NTP, F16, M>), dim3(nunits), dim3(128), 0, st, pl->d_params,         \
                                pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
