@@ -75,6 +75,12 @@ __device__ __forceinline__ f64x4 mfma4d(double a, double b, f64x4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 blocks, D_b[i][j] += A_b[i] B_b[j]; lane l belongs to block l / 4,
+// supplies A_b[l % 4] and B_b[l % 4] and holds D_b[register][l % 4] (tools/probe/mfma_layout.hip); 8 cycles.
+__device__ __forceinline__ f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ f32x4 zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;
@@ -268,11 +274,14 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
-    // N = 17..20: the BB block of the 2x2-blocked Gram is only 4 x 4.  A 16x16x4 MFMA per k-step for it wastes 15/16
-    // of the matrix pipe, and pass 1 at N = 20 is MFMA-issue-bound (SQ_WAIT_INST_ANY 69 %, MFMA busy 58 %): the ten
-    // products of tasks 16..19 are taken on the vector ALU from the registers the centred rows are still in.
+    // N = 17..20: of the 2x2-blocked Gram only AA is a full 16 x 16 tile; AB is 16 x 4 and BB 4 x 4.  A 16x16x4 MFMA per
+    // k-step for each of them wastes 3/4 and 15/16 of the matrix pipe, and pass 1 at N = 20 is MFMA-issue-bound
+    // (SQ_WAIT_INST_ANY 69 %, MFMA busy 58 %).  They are taken by v_mfma_f32_4x4x1_16b_f32 instead -- sixteen 4x4 outer
+    // products per instruction, 8 cycles:  AB: block (mg, rg) = tasks 4mg..4mg+3 x tasks 16..19 on row 4rg + e of the
+    // sub-tile (four instructions per 16 rows);  BB: block b = row b of the sub-tile (one instruction per 16 rows).
+    // 2 688 matrix-pipe cycles per 256-row block instead of 4 096 plus the vector-ALU corner.
     constexpr bool VBB = (NTP == 20) && !F64;
-    constexpr int NACC = (NB == 1) ? 1 : (VBB ? 2 : 3);  // AA | AA, AB, BB
+    constexpr int NACC = (NB == 1 || VBB) ? 1 : 3;  // AA | AA, AB, BB
 
     const int lane = threadIdx.x & 63;
     const SvdqUnit ud = units[uidx];
@@ -302,9 +311,12 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
 #pragma unroll
     for (int i = 0; i < NACC * QC; ++i) accq[i] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    double bbd[VBB ? 10 : 1];  // per-lane partial products of tasks (16+a, 16+b), a <= b
+    double qd[2][4];  // VBB: AB and BB block partials of the 4x4x1 chains (fp32 inside a block, fp64 across)
 #pragma unroll
-    for (int i = 0; i < (VBB ? 10 : 1); ++i) bbd[i] = 0.0;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qd[i][e] = 0.0;
+    const int b4 = lane >> 2, i4 = lane & 3, mg4 = b4 & 3, rg4 = b4 >> 2;
 
     // The loads of the next block (or next two, SVDQ_PREFETCH2) are in flight while a block is computed.
     constexpr int AHEAD = SVDQ_PREFETCH2 ? 2 : 1;
@@ -340,19 +352,6 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
         }
         center_store<NTP, GATHER>(v, NT, center, X, lane);
         wave_sync();
-        if constexpr (VBB) {  // rows 4 lane .. 4 lane + 3 of tasks 16..19, read back from the strip so that the
-            f32x4 xe[4];      // grouping of rows per lane (and with it every bit) is the same in gather mode
-#pragma unroll
-            for (int a = 0; a < 4; ++a) xe[a] = *reinterpret_cast<const f32x4 *>(X + (16 + a) * XS + 4 * lane);
-            int q = 0;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = a; b < 4; ++b) {
-                    const f32x4 pr = xe[a] * xe[b];
-                    bbd[q++] += (double)((pr.x + pr.y) + (pr.z + pr.w));
-                }
-        }
         if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
             if constexpr (GATHER) {
                 load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
@@ -367,6 +366,7 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
         f32x4 acc[NACC];
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = zero4();
+        f32x4 qab = zero4(), qbb = zero4();
 
         if constexpr (PACK == 2) {
             const int t = c & 7;
@@ -415,6 +415,15 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
                 } else if constexpr (NB == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[0] = mfma4(a0[e], a0[e], acc[0]);
+                } else if constexpr (VBB) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[0] = mfma4(a0[e], a0[e], acc[0]);
+                    const f32x4 xa = *reinterpret_cast<const f32x4 *>(X + (4 * mg4 + i4) * XS + 16 * j + 4 * rg4);
+                    const f32x4 xq = *reinterpret_cast<const f32x4 *>(X + (16 + i4) * XS + 16 * j + 4 * rg4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) qab = mfma_4x4x1(xa[e], xq[e], qab);
+                    const float xr = X[(16 + i4) * XS + 16 * j + b4];
+                    qbb = mfma_4x4x1(xr, xr, qbb);
                 } else {
                     f32x4 a1 = *reinterpret_cast<const f32x4 *>(x1 + 16 * j);
                     if (!v1ok) a1 = zero4();
@@ -422,7 +431,7 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
                     for (int e = 0; e < 4; ++e) {
                         acc[0] = mfma4(a0[e], a0[e], acc[0]);
                         acc[1] = mfma4(a0[e], a1[e], acc[1]);
-                        if constexpr (!VBB) acc[2] = mfma4(a1[e], a1[e], acc[2]);
+                        acc[2] = mfma4(a1[e], a1[e], acc[2]);
                     }
                 }
             }
@@ -432,6 +441,13 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
             for (int i = 0; i < NACC; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) accd[i][e] += (double)acc[i][e];
+            if constexpr (VBB) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    qd[0][e] += (double)qab[e];
+                    qd[1][e] += (double)qbb[e];
+                }
+            }
         }
         wave_sync();
     };
@@ -470,30 +486,32 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
         for (int e = 0; e < 4; ++e) {
             const int m = F64 ? g + 4 * e : 4 * g + e;
             if (m < NT && c < NT) dst[m * NT + c] = accd[0][e];
-            if constexpr (NB == 2) {
+            if constexpr (NB == 2 && !VBB) {
                 if (m < NT && 16 + c < NT) {
                     dst[m * NT + 16 + c] = accd[1][e];
                     dst[(16 + c) * NT + m] = accd[1][e];
                 }
-                if constexpr (!VBB) {
-                    if (16 + m < NT && 16 + c < NT) dst[(16 + m) * NT + 16 + c] = accd[2][e];
-                }
+                if (16 + m < NT && 16 + c < NT) dst[(16 + m) * NT + 16 + c] = accd[2][e];
             }
         }
-        if constexpr (VBB) {  // butterfly sum of the per-lane BB partials (fixed order), written once
-            int q = 0;
+        if constexpr (VBB) {   // block partials meet in fixed-order shuffles
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = a; b < 4; ++b) {
-                    double t = bbd[q++];
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-                    if (lane == 0 && 16 + b < NT) {   // a <= b, so 16 + a < NT as well
-                        dst[(16 + a) * NT + 16 + b] = t;
-                        dst[(16 + b) * NT + 16 + a] = t;
-                    }
+            for (int e = 0; e < 4; ++e) {
+                // AB: lane (block (mg, rg), j) register e = [task 4mg + e][task 16 + j] over the rows of row group rg
+                double x = qd[0][e];
+                x += __shfl_xor(x, 16);
+                x += __shfl_xor(x, 32);
+                const int m = 4 * mg4 + e;
+                if (rg4 == 0 && m < NT && 16 + i4 < NT) {
+                    dst[m * NT + 16 + i4] = x;
+                    dst[(16 + i4) * NT + m] = x;
                 }
+                // BB: lane (block b, j) register e = [task 16 + e][task 16 + j] over the rows b mod 16
+                double y = qd[1][e];
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) y += __shfl_xor(y, off);
+                if (b4 == 0 && 16 + e < NT && 16 + i4 < NT) dst[(16 + e) * NT + 16 + i4] = y;
+            }
         }
     }
 }
@@ -1154,9 +1172,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) f32x2 gf32x2;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
-}
 __device__ __forceinline__ s16x4 pack_bf16x4(const f32x4 &x) {
     union { __bf16 h[4]; s16x4 v; } u;
 #pragma unroll
