@@ -282,6 +282,13 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     // 2 688 matrix-pipe cycles per 256-row block instead of 4 096 plus the vector-ALU corner.
     constexpr bool VBB = (NTP == 20) && !F64;
     constexpr int NACC = (NB == 1 || VBB) ? 1 : 3;  // AA | AA, AB, BB
+    // N = 5..8 with exact products: the 8 x 8 Gram is four 4 x 4 tiles, which is exactly one v_mfma_f64_4x4x4_4b_f64
+    // (four blocks, K = 4 rows, 16 cycles) -- the 16x16x4 form spends 64 cycles on two useful 8 x 8 corners of a 16 x 16
+    // tile.  Layout probed on the device (tools/probe/mfma_f64_layout.hip): lane l = (k = l >> 4, b = (l >> 2) & 3,
+    // x = l & 3) supplies A_b[x][k] and B_b[k][x] and holds D_b[i = l >> 4][j = l & 3]; block b = tile (b >> 1, b & 1).
+    // The lane's k selects rows 4k..4k+3 of a 16-row sub-tile (one 16-byte LDS read per operand), the four
+    // instructions of a sub-tile take one of them each.  1 024 instead of 2 048 matrix-pipe cycles per block.
+    constexpr bool Q64 = F64 && (NTP == 8);
 
     const int lane = threadIdx.x & 63;
     const SvdqUnit ud = units[uidx];
@@ -311,6 +318,7 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
 #pragma unroll
     for (int i = 0; i < NACC * QC; ++i) accq[i] = f64x4{0.0, 0.0, 0.0, 0.0};
 
+    double q64 = 0.0;   // Q64: this lane's Gram entry, accumulated over the whole unit
     double qd[2][4];  // VBB: AB and BB block partials of the 4x4x1 chains (fp32 inside a block, fp64 across)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -368,7 +376,19 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
         for (int i = 0; i < NACC; ++i) acc[i] = zero4();
         f32x4 qab = zero4(), qbb = zero4();
 
-        if constexpr (PACK == 2) {
+        if constexpr (Q64) {
+            const int kq = lane >> 4, bq = (lane >> 2) & 3, xq = lane & 3;
+            const float *pa = X + (4 * (bq >> 1) + xq) * XS + 4 * kq;
+            const float *pb = X + (4 * (bq & 1) + xq) * XS + 4 * kq;
+UNROLL_N(SVDQ_UNROLL_GRAM)
+            for (int j = 0; j < 16; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(pa + 16 * j);
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(pb + 16 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    q64 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a[e], (double)b[e], q64, 0, 0, 0);
+            }
+        } else if constexpr (PACK == 2) {
             const int t = c & 7;
             const bool valid = t < NTP;
             const float *xr = X + (valid ? t : 0) * XS + 16 * (c >> 3) + 4 * g;
@@ -472,7 +492,15 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
 
     // One fp64 partial per slot, dense [NT][NT].  Lane (c,g) holds D[4g+e][c] (fp32 MFMA) or D[g+4e][c] (fp64 MFMA).
     const int NN = NT * NT;
-    if constexpr (PACK == 2) {
+    if constexpr (Q64) {   // the whole 8 x 8 in the unit's first slot, zeros in its second
+        const int i = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
+        const int m = 4 * (bq >> 1) + i, n = 4 * (bq & 1) + jq;
+        double *dst = gram_part + (size_t)uidx * 2 * NN;
+        if (m < NT && n < NT) {
+            dst[m * NT + n] = q64;
+            dst[NN + m * NT + n] = 0.0;
+        }
+    } else if constexpr (PACK == 2) {
         const int rs = c >> 3, n = c & 7;
         double *dst = gram_part + ((size_t)uidx * 2 + rs) * NN;
 #pragma unroll
