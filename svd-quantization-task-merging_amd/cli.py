@@ -54,10 +54,10 @@ def run_svd_hybrid_pipeline(config: SVDHybridConfig) -> Dict:
     base_state_dict = load_checkpoint(config.base_model_path, device="cpu")
     paths = get_task_checkpoint_paths(config.checkpoint_dir, config.tasks)
     has_masks = bool(config.mask_dir) and os.path.exists(config.mask_dir)
-    # Nothing downstream needs the task vectors themselves when there are no masks, no clustering and no
-    # reconstruction diagnostics: then finetuned - base is formed inside the two streaming passes
-    # (svdq_compress_from_base) and the deltas are never materialised.
-    from_checkpoints = (not has_masks) and config.svd_weighting != "cluster" and not config.svd_eval_reconstruction
+    # Nothing downstream needs the task vectors themselves when there is no clustering and no reconstruction
+    # diagnostics: then finetuned - base is formed inside the two streaming passes (svdq_compress_from_base; masked
+    # parameters through svdq_compress_gather_from_base) and the deltas are never materialised.
+    from_checkpoints = config.svd_weighting != "cluster" and not config.svd_eval_reconstruction
     if from_checkpoints:
         float_base = {k: v for k, v in base_state_dict.items() if isinstance(v, torch.Tensor) and v.is_floating_point()}
         task_vectors = {}
@@ -94,7 +94,8 @@ def run_svd_hybrid_pipeline(config: SVDHybridConfig) -> Dict:
 
     print("[4-5/8] bases + compression (svdq_compress)")
     if from_checkpoints:   # task_vectors holds the fine-tuned weights here (same names and shapes as the deltas)
-        bases, compressed_all = run_basis_and_compress_from_checkpoints(float_base, task_vectors, config, device)
+        bases, compressed_all = run_basis_and_compress_from_checkpoints(float_base, task_vectors, config, device,
+                                                                        combined_masks=combined_masks)
     else:
         bases, compressed_all = run_basis_and_compress(task_vectors, combined_masks, config, device)
     stats = compute_compression_statistics(task_vectors, compressed_all, bases, config)

@@ -162,13 +162,17 @@ def test_packed_tall_mask_file_route(sq, tmp_path, strategy):
         assert b["D"] == int(want[k].sum()) and b["U_high"].shape[0] == b["D"]
 
 
-def test_cli_from_checkpoints_route_matches(sq, tmp_path):
-    """--no-eval-reconstruction without masks or clustering: the driver compresses straight from the fine-tuned and
-    base weights (no task vectors in HBM); the merged model is the same, bit for bit, as on the ordinary route."""
+@pytest.mark.parametrize("with_masks", [False, True])
+def test_cli_from_checkpoints_route_matches(sq, tmp_path, with_masks):
+    """--no-eval-reconstruction without clustering: the driver compresses straight from the fine-tuned and base weights
+    (no task vectors in HBM; masked parameters through gather + minus-base in one pass); the merged model is the same,
+    bit for bit, as on the ordinary route."""
     tasks = ["Cars", "DTD", "EuroSAT", "GTSRB", "MNIST", "SVHN"]
-    base, shapes, deltas = _write_checkpoints(tmp_path, tasks, with_masks=False)
+    base, shapes, deltas = _write_checkpoints(tmp_path, tasks, with_masks=with_masks)
     common = ["--tasks", *tasks, "--checkpoint-dir", str(tmp_path / "ckpt"), "--base-model-path", str(tmp_path / "base.pt"),
               "--energy-threshold", "0.9", "--max-rank", "2", "--store-artifacts"]
+    if with_masks:
+        common += ["--mask-dir", str(tmp_path / "masks"), "--include-noise"]
     a = sq.cli.main(common + ["--output-dir", str(tmp_path / "o1"), "--artifact-dir", str(tmp_path / "a1")])
     b = sq.cli.main(common + ["--no-eval-reconstruction", "--output-dir", str(tmp_path / "o2"), "--artifact-dir",
                               str(tmp_path / "a2")])
