@@ -288,7 +288,18 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     // x = l & 3) supplies A_b[x][k] and B_b[k][x] and holds D_b[i = l >> 4][j = l & 3]; block b = tile (b >> 1, b & 1).
     // The lane's k selects rows 4k..4k+3 of a 16-row sub-tile (one 16-byte LDS read per operand), the four
     // instructions of a sub-tile take one of them each.  1 024 instead of 2 048 matrix-pipe cycles per block.
-    constexpr bool Q64 = F64 && (NTP == 8);
+    // The same instruction serves every N <= 16 (T = NTP / 4 tile rows): only the T (T + 1) / 2 tiles on or above the
+    // diagonal are computed, four per instruction -- T = 1: the four blocks take four different 16-row groups of the
+    // one tile (summed at the end); T = 2: all four tiles in one instruction; T = 3: six tiles in two instructions;
+    // (T = 4: ten tiles in three, was measured SLOWER than the 16x16x4 form -- 4.62 against 3.58 ms at ViT-L-14 x 16:
+    // every 4x4x4 instruction needs two converted operands per lane, eight times the v_cvt_f64_f32 work per output --
+    // so N = 13..16 stays on 16x16x4.)  Matrix-pipe cycles per four rows: 4 / 16 / 32 against 64 for the 16x16x4 form,
+    // which at N <= 4 made pass 1 matrix-bound (1.52 -> 0.52 ms for the 2.4 GB of ViT-L-14 x 2; N = 4: 1.58 -> 0.83;
+    // N = 12: 3.21 -> 2.98).
+    constexpr bool Q64 = F64 && (NTP <= 12);
+    constexpr int TQ = NTP / 4;
+    constexpr int NTILE = TQ * (TQ + 1) / 2;
+    constexpr int NSET = (TQ == 2) ? 1 : (NTILE + 3) / 4;   // T = 2 keeps its redundant (1,0) tile: one instruction anyway
 
     const int lane = threadIdx.x & 63;
     const SvdqUnit ud = units[uidx];
@@ -318,7 +329,20 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
 #pragma unroll
     for (int i = 0; i < NACC * QC; ++i) accq[i] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    double q64 = 0.0;   // Q64: this lane's Gram entry, accumulated over the whole unit
+    double q64[Q64 ? NSET : 1];   // Q64: this lane's Gram entries (one per instruction of a step), over the whole unit
+#pragma unroll
+    for (int i = 0; i < (Q64 ? NSET : 1); ++i) q64[i] = 0.0;
+    // tile (ti <= tj) number q in row-major order of the upper triangle
+    auto tile_of = [](int q, int &ti, int &tj) {
+        ti = 0;
+        int rowlen = TQ;
+        while (q >= rowlen) {
+            q -= rowlen;
+            --rowlen;
+            ++ti;
+        }
+        tj = ti + q;
+    };
     double qd[2][4];  // VBB: AB and BB block partials of the 4x4x1 chains (fp32 inside a block, fp64 across)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -378,15 +402,44 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
 
         if constexpr (Q64) {
             const int kq = lane >> 4, bq = (lane >> 2) & 3, xq = lane & 3;
-            const float *pa = X + (4 * (bq >> 1) + xq) * XS + 4 * kq;
-            const float *pb = X + (4 * (bq & 1) + xq) * XS + 4 * kq;
-UNROLL_N(SVDQ_UNROLL_GRAM)
-            for (int j = 0; j < 16; ++j) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(pa + 16 * j);
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(pb + 16 * j);
+            if constexpr (TQ == 1) {
+                // one tile: block b takes rows 16b..16b+15 of every 64-row group; A and B are the same value
+                const float *pa = X + xq * XS + 16 * bq + 4 * kq;
+UNROLL_N(4)
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(pa + 64 * j);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    q64 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a[e], (double)b[e], q64, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        const double ad = (double)a[e];
+                        q64[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, ad, q64[0], 0, 0, 0);
+                    }
+                }
+            } else {
+                const float *pa[NSET], *pb[NSET];
+#pragma unroll
+                for (int st = 0; st < NSET; ++st) {
+                    int ti, tj;
+                    if constexpr (TQ == 2) {
+                        ti = bq >> 1;
+                        tj = bq & 1;
+                    } else {
+                        const int q = 4 * st + bq;
+                        tile_of(q < NTILE ? q : NTILE - 1, ti, tj);   // spare blocks repeat the last tile, unused
+                    }
+                    pa[st] = X + (4 * ti + xq) * XS + 4 * kq;
+                    pb[st] = X + (4 * tj + xq) * XS + 4 * kq;
+                }
+UNROLL_N(SVDQ_UNROLL_GRAM)
+                for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                    for (int st = 0; st < NSET; ++st) {
+                        const f32x4 a = *reinterpret_cast<const f32x4 *>(pa[st] + 16 * j);
+                        const f32x4 b = *reinterpret_cast<const f32x4 *>(pb[st] + 16 * j);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            q64[st] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a[e], (double)b[e], q64[st], 0, 0, 0);
+                    }
+                }
             }
         } else if constexpr (PACK == 2) {
             const int t = c & 7;
@@ -492,13 +545,37 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
 
     // One fp64 partial per slot, dense [NT][NT].  Lane (c,g) holds D[4g+e][c] (fp32 MFMA) or D[g+4e][c] (fp64 MFMA).
     const int NN = NT * NT;
-    if constexpr (Q64) {   // the whole 8 x 8 in the unit's first slot, zeros in its second
+    if constexpr (Q64) {   // everything in the unit's first slot; N <= 8 has a second slot per unit: zeros
         const int i = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
-        const int m = 4 * (bq >> 1) + i, n = 4 * (bq & 1) + jq;
-        double *dst = gram_part + (size_t)uidx * 2 * NN;
-        if (m < NT && n < NT) {
-            dst[m * NT + n] = q64;
-            dst[NN + m * NT + n] = 0.0;
+        double *dst = gram_part + (size_t)uidx * PACK * NN;
+        if constexpr (TQ == 1) {
+            double x = q64[0];
+            x += __shfl_xor(x, 4);
+            x += __shfl_xor(x, 8);
+            if (bq == 0 && i < NT && jq < NT) {
+                dst[i * NT + jq] = x;
+                dst[NN + i * NT + jq] = 0.0;
+            }
+        } else if constexpr (TQ == 2) {
+            const int m = 4 * (bq >> 1) + i, n = 4 * (bq & 1) + jq;
+            if (m < NT && n < NT) {
+                dst[m * NT + n] = q64[0];
+                dst[NN + m * NT + n] = 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int st = 0; st < NSET; ++st) {
+                const int q = 4 * st + bq;
+                if (q < NTILE) {
+                    int ti, tj;
+                    tile_of(q, ti, tj);
+                    const int m = 4 * ti + i, n = 4 * tj + jq;
+                    if (m < NT && n < NT) {
+                        dst[m * NT + n] = q64[st];
+                        if (ti != tj) dst[n * NT + m] = q64[st];
+                    }
+                }
+            }
         }
     } else if constexpr (PACK == 2) {
         const int rs = c >> 3, n = c & 7;
