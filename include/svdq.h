@@ -237,6 +237,14 @@ int svdq_rtvq_quantize(const float *x_dev, int64_t n, int32_t bits, int32_t stag
 int svdq_rtvq_dequantize(const uint8_t *codes_dev, int64_t code_stride, int64_t n, int32_t stages,
                          const float *scale_dev, const float *zp_dev, float *out_dev, void *stream);
 
+/*      qbit = 16 (asymmetric_quantization rtvq.py:22-25 only; SVDHybridConfig allows at most 8 bits): one stage, int16
+ *      codes exactly as the reference's CPU cast leaves them (values above 32767 wrap negative), and the matching
+ *      asymmetric_dequantization on int16 input.  work_dev: svdq_rtvq_work_bytes(n) bytes. */
+int svdq_asym16_quantize(const float *x_dev, int64_t n, int16_t *codes_dev, float *scale_dev, float *zp_dev,
+                         void *work_dev, void *stream);
+int svdq_asym16_dequantize(const int16_t *codes_dev, int64_t n, const float *scale_dev, const float *zp_dev,
+                           float *out_dev, void *stream);
+
 /* ---- standalone projection for callers that bring their own basis
  *      (project_to_basis compress.py:6-21 with the mean subtraction of compress.py:35-37):
  *      c_out[i] = sum_d float(U[d][i]) * (delta[d] - mean[d]),  i < k from U_high [rows,k],

@@ -69,6 +69,8 @@ SIGNATURES = {
     "svdq_rtvq_quantize": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
     "svdq_rtvq_dequantize": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_asym16_quantize": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_asym16_dequantize": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_mask_work_bytes": (c_int64, [c_int64]),
     "svdq_mask_combine": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_mask_compact": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p,

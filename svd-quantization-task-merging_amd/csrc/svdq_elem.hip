@@ -292,6 +292,66 @@ extern "C" int svdq_rtvq_dequantize(const uint8_t *codes, int64_t code_stride, i
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
+// ---- qbit = 16 (rtvq.py:22-25): single stage, int16 codes.  The reference casts the clamped fp32 value (0 .. 65535) to
+// torch.int16; on the CPU that goes through a 32-bit integer and keeps the low 16 bits, so codes above 32767 come out
+// negative -- reproduced as is (tests/golden/rtvq_cases.npz holds the reference's values).
+__global__ __launch_bounds__(ELT_THREADS) void k_asym16_apply(const float *__restrict__ x, int64_t n,
+                                                              const RtvqPartial *__restrict__ part, int nblk,
+                                                              int16_t *__restrict__ codes, float *__restrict__ scale_out,
+                                                              float *__restrict__ zp_out) {
+    float scale, zp, rnorm;
+    stage_params(part, nblk, 16, scale, zp, rnorm);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scale_out[0] = scale;
+        zp_out[0] = zp;
+    }
+    const int64_t stride = (int64_t)gridDim.x * ELT_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x; i < n; i += stride) {
+        float vq = rintf(__fadd_rn(__fmul_rn(scale, x[i]), zp));
+        int32_t q = 0;
+        if (vq == vq) {
+            vq = vq < 0.f ? 0.f : (vq > 65535.f ? 65535.f : vq);
+            q = (int32_t)vq;
+        }
+        codes[i] = (int16_t)(uint16_t)q;
+    }
+}
+
+__global__ __launch_bounds__(ELT_THREADS) void k_asym16_dequant(const int16_t *__restrict__ codes, int64_t n,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ zp, float *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * ELT_THREADS;
+    const float sc = scale[0], z = zp[0];
+    for (int64_t i = (int64_t)blockIdx.x * ELT_THREADS + threadIdx.x; i < n; i += stride)
+        out[i] = __fdiv_rn(__fsub_rn((float)codes[i], z), sc);   // rtvq.py:35 on the int16 values as they are
+}
+
+extern "C" int svdq_asym16_quantize(const float *x, int64_t n, int16_t *codes, float *scale, float *zp, void *work,
+                                    void *stream) {
+    if (n < 1 || !x || !codes || !scale || !zp || !work || (reinterpret_cast<uintptr_t>(x) & 15) ||
+        (reinterpret_cast<uintptr_t>(work) & 255)) {
+        svdq_set_error("svdq_asym16_quantize: bad argument (n >= 1, x 16-byte aligned, work 256-byte aligned)");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    RtvqPartial *part = reinterpret_cast<RtvqPartial *>(reinterpret_cast<uint8_t *>(work) + svdq_align_up(n * 4, 256));
+    const int grid = rtvq_grid(n);
+    hipLaunchKernelGGL(k_rtvq_stats, dim3(grid), dim3(ELT_THREADS), 0, st, x, n, part);
+    hipLaunchKernelGGL(k_asym16_apply, dim3(grid), dim3(ELT_THREADS), 0, st, x, n, part, grid, codes, scale, zp);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+extern "C" int svdq_asym16_dequantize(const int16_t *codes, int64_t n, const float *scale, const float *zp, float *out,
+                                      void *stream) {
+    if (n < 1 || !codes || !scale || !zp || !out) {
+        svdq_set_error("svdq_asym16_dequantize: bad argument");
+        return SVDQ_EINVAL;
+    }
+    hipLaunchKernelGGL(k_asym16_dequant, dim3(rtvq_grid(n)), dim3(ELT_THREADS), 0, (hipStream_t)stream, codes, n, scale,
+                       zp, out);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
 // ------------------------------------------------------------------------------------ masks
 #define MASK_TILE 2048  // elements per block: 256 threads x 8
 

@@ -38,10 +38,21 @@ def _quantize_device(x: torch.Tensor, bits: int, stages: int):
 def asymmetric_quantization(X: torch.Tensor, qbit: int = 8, verbose: bool = False
                             ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Reference rtvq.py:4-27: (uint8 codes shaped like X, 0-d scale, 0-d zero_point), on X's device."""
-    if qbit > 8:
-        raise ValueError("only qbit <= 8 (uint8 codes) is supported on the HIP path")
+    if qbit > 8 and qbit != 16:
+        # the reference falls off the end of its dtype selection here (UnboundLocalError, rtvq.py:22-27)
+        raise ValueError(f"qbit must be <= 8 or 16, got {qbit}")
     dev = resolve_device(X.device if X.is_cuda else "cuda")
     x = prepare_vector(X, dev)
+    if qbit == 16:   # int16 codes, exactly as the reference's cast leaves them (values above 32767 wrap negative)
+        lib = nat.lib()
+        n = x.numel()
+        codes = torch.empty(n, dtype=torch.int16, device=dev)
+        sz = torch.empty(2, dtype=torch.float32, device=dev)
+        work = torch.empty(int(lib.svdq_rtvq_work_bytes(n)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.svdq_asym16_quantize(_ptr(x), n, _ptr(codes), _ptr(sz[0:1]), _ptr(sz[1:2]), _ptr(work),
+                                               _stream_ptr()), "svdq_asym16_quantize")
+        return codes.view(X.shape).to(X.device), sz[0].to(X.device), sz[1].to(X.device)
     codes, scale, zp, _ = _quantize_device(x, qbit, 1)
     out_dev = X.device
     return codes[0].contiguous().view(X.shape).to(out_dev), scale[0].to(out_dev), zp[0].to(out_dev)
@@ -49,6 +60,19 @@ def asymmetric_quantization(X: torch.Tensor, qbit: int = 8, verbose: bool = Fals
 
 def asymmetric_dequantization(quantized: torch.Tensor, scale: torch.Tensor, zero_point: torch.Tensor) -> torch.Tensor:
     """Reference rtvq.py:29-36: (q.float() - zero_point) / scale."""
+    if quantized.dtype == torch.int16:
+        lib = nat.lib()
+        out_dev = quantized.device
+        dev = resolve_device(out_dev if quantized.is_cuda else "cuda")
+        q = quantized.to(dev).contiguous().view(-1)
+        sz = torch.stack([torch.as_tensor(scale, dtype=torch.float32).reshape(()),
+                          torch.as_tensor(zero_point, dtype=torch.float32).reshape(())]).to(dev)
+        out = torch.empty(q.numel(), dtype=torch.float32, device=dev)
+        if q.numel():
+            with torch.cuda.device(dev):
+                nat.check(lib.svdq_asym16_dequantize(_ptr(q), q.numel(), _ptr(sz[0:1]), _ptr(sz[1:2]), _ptr(out),
+                                                     _stream_ptr()), "svdq_asym16_dequantize")
+        return out.view(quantized.shape).to(out_dev)
     return _dequantize([quantized], [scale], [zero_point], quantized.device)
 
 

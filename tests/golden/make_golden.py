@@ -127,6 +127,15 @@ def gen_rtvq():
             cases[tag + "deq"] = ref_rtvq.asymmetric_dequantization(q, sc, zp).numpy()
             d2 = ref_qutils.dequantize_asymmetric(q2, sc2, zp2).numpy()
             assert np.array_equal(cases[tag + "deq"], d2, equal_nan=True)
+    # qbit = 16 (rtvq.py:22-25): int16 codes straight from the reference's cast (values above 32767 wrap)
+    for name in ("n19", "n100", "n4096", "ramp5"):
+        q, sc, zp = ref_rtvq.asymmetric_quantization(inputs[name], 16)
+        assert q.dtype == torch.int16
+        tag = f"{name}__asym16__"
+        cases[tag + "q"] = q.numpy()
+        cases[tag + "scale"] = np.float32(sc.item())
+        cases[tag + "zero_point"] = np.float32(zp.item())
+        cases[tag + "deq"] = ref_rtvq.asymmetric_dequantization(q, sc, zp).numpy()
     empty = ref_rtvq.RTVQQuantizer(4, 2).quantize(torch.tensor([]))
     assert empty["payloads"] == []
     cases["empty__deq_numel"] = np.int64(ref_rtvq.RTVQQuantizer(4, 2).dequantize(empty).numel())

@@ -66,6 +66,22 @@ def test_rtvq_bit_exact_vs_reference_vectors(sq):
             assert bits_equal(sq.asymmetric_dequantization(q, sc, zp).numpy(), g[tag + "deq"])
 
 
+def test_asymmetric_quantization_16_bits_vs_reference_vectors(sq):
+    """rtvq.py:22-25: qbit = 16 gives int16 codes; the reference's CPU cast keeps the low 16 bits of the clamped
+    0..65535 value, so codes above 32767 come out negative and dequantize wrongly -- reproduced bit for bit."""
+    g = load_golden("rtvq_cases.npz")
+    for name in ("n19", "n100", "n4096", "ramp5"):
+        x = torch.from_numpy(g[f"{name}__x"])
+        q, sc, zp = sq.asymmetric_quantization(x, 16)
+        assert q.dtype == torch.int16 and q.shape == x.shape
+        assert np.array_equal(q.numpy(), g[f"{name}__asym16__q"]), name
+        assert bits_equal(np.float32(sc.item()), g[f"{name}__asym16__scale"])
+        assert bits_equal(np.float32(zp.item()), g[f"{name}__asym16__zero_point"])
+        assert bits_equal(sq.asymmetric_dequantization(q, sc, zp).numpy(), g[f"{name}__asym16__deq"]), name
+    with pytest.raises(ValueError, match="qbit"):
+        sq.asymmetric_quantization(torch.randn(8), 12)
+
+
 def test_rtvq_empty(sq):
     obj = sq.RTVQQuantizer(4, 2).quantize(torch.tensor([]))
     assert obj["payloads"] == []
