@@ -108,7 +108,8 @@ _lib = None
 
 
 def build(verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into the in-tree libsvdq_hip.so (csrc/Makefile)."""
+    """Compile every HIP source for gfx950 into the in-tree libsvdq_hip.so, and the TORCH_LIBRARY operator shim
+    into libsvdq_torch.so (csrc/Makefile)."""
     cmd = ["make", "-C", _CSRC, "-j4"]
     res = subprocess.run(cmd, capture_output=not verbose, text=True)
     if res.returncode != 0:

@@ -40,6 +40,22 @@ def test_header_matches_exports_and_binding(sq):
         assert hasattr(lib, name)
 
 
+def test_operator_library_binds_only_the_public_abi(sq):
+    """libsvdq_torch.so (TORCH_LIBRARY registrations of torch.ops.svdq.*) reaches the kernels through include/svdq.h
+    alone: every svdq_* symbol it imports is a declared entry point, and it defines none of its own."""
+    path = sq.torch_ops.OPS_LIB_PATH
+    assert os.path.exists(path)
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", path], text=True)
+    used = sorted({ln.split()[-1] for ln in und.splitlines() if " U svdq_" in ln})
+    assert used and set(used) <= set(_header_functions()), used
+    for must in ("svdq_compress", "svdq_rtvq_quantize", "svdq_mask_combine", "svdq_ingest", "svdq_task_gram"):
+        assert must in used
+    defd = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    assert not [ln for ln in defd.splitlines() if " T svdq_" in ln]
+    needed = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-d", path], text=True)
+    assert "libsvdq_hip.so" in needed and "$ORIGIN" in needed
+
+
 def test_every_entry_point_cites_the_reference():
     text = open(os.path.join(ROOT, "include", "svdq.h")).read()
     for ref_file in ("basis.py", "compress.py", "rtvq.py", "mask_loader.py", "cli.py", "config.py",

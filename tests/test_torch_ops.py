@@ -8,6 +8,25 @@ import svdq_amd  # noqa: F401  (registers the operators)
 OPS = ("rtvq_quantize", "rtvq_dequantize", "mask_combine", "mask_select", "compress", "ingest", "task_gram")
 
 
+def test_ops_are_registered_natively():
+    """The operators come from libsvdq_torch.so (TORCH_LIBRARY in csrc/svdq_torch.cpp), which is linked against
+    the in-tree libsvdq_hip.so; no Python function stands behind any of them."""
+    import os
+    from svdq_amd import torch_ops, _native
+    assert os.path.exists(torch_ops.OPS_LIB_PATH)
+    mapped = open("/proc/self/maps").read()
+    assert os.path.realpath(torch_ops.OPS_LIB_PATH) in mapped and os.path.realpath(_native.LIB_PATH) in mapped
+    assert mapped.count("libsvdq_hip.so") and len({l.split()[-1] for l in mapped.splitlines()
+                                                   if l.endswith("libsvdq_hip.so")}) == 1   # one copy, not two
+    for name in OPS:
+        schema = getattr(torch.ops.svdq, name).default._schema
+        assert schema.name == f"svdq::{name}"
+        # a Python-registered kernel shows up in torch.library's registry of the process; none may
+        assert not torch._C._dispatch_has_kernel_for_dispatch_key(f"svdq::{name}", "CPU")
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f"svdq::{name}", "CUDA")
+    assert torch_ops.plan_cache_size() >= 0
+
+
 def test_ops_are_registered_and_have_no_cpu_kernel():
     for name in OPS:
         assert hasattr(torch.ops.svdq, name), name
@@ -47,10 +66,10 @@ def test_ops_match_the_python_layer():
     # a second call with the same shapes reuses the cached plan: no new plan, fresh outputs, same bits, and the
     # first call's outputs are untouched
     from svdq_amd import torch_ops
-    n_plans = len(torch_ops._PLAN_CACHE)
+    n_plans = torch_ops.plan_cache_size()
     small_copy = small.clone()
     small2, basis2, mean2 = torch.ops.svdq.compress([v for vs in vecs for v in vs], N, 0.9, 0, True, True, 4, 2)
-    assert len(torch_ops._PLAN_CACHE) == n_plans and small2.data_ptr() != small.data_ptr()
+    assert torch_ops.plan_cache_size() == n_plans and small2.data_ptr() != small.data_ptr()
     torch.cuda.synchronize()
     assert torch.equal(small2, small_copy) and torch.equal(small, small_copy)
     for p, D in enumerate(sizes):              # the packed buffers have uninitialised alignment gaps: compare views
