@@ -69,12 +69,16 @@ def parse():
     ap.add_argument("--from-base", choices=("off", "fused", "ingest"), default="off",
                     help="start from fine-tuned + base weights instead of task vectors: 'fused' forms finetuned - base "
                          "inside the streaming passes (svdq_compress_from_base), 'ingest' runs svdq_ingest first")
-    ap.add_argument("--placement-candidates", type=int, default=1,
-                    help="> 1: before timing, keep the fastest of this many candidate allocations for the output basis "
-                         "(CompressPlan.tune_placement).  Default 1 = the first allocation as it comes, which is what "
-                         "driver.run_basis_and_compress delivers")
+    ap.add_argument("--placement-candidates", type=int, default=6,
+                    help="> 1: once, before the timed region, CompressPlan.tune_placement walks this many candidate "
+                         "output allocations through the memory regions (HBM ranks) of the device and keeps the "
+                         "basis and the mean buffer pass 2 runs fastest into (DESIGN.md section 5: which region each "
+                         "stream lives in decides 2.72 vs 3.1 ms).  The same K steps are also timed BEFORE it, on the "
+                         "first allocation as it comes, and reported as `untuned`.  1 = no tuning")
     ap.add_argument("--gram32", action="store_true",
                     help="A/B: fp32-product Gram in pass 1 (the round-1 kernel) instead of the fp64-MFMA Gram")
+    ap.add_argument("--xcd", action="store_true",
+                    help="A/B: XCD-chunked unit order in both passes (each XCD walks a contiguous eighth of the units)")
     ap.add_argument("--bp2", action="store_true",
                     help="A/B, N = 17..20: the two-wave pass 2 (round 1) instead of the one-wave 4x4-block kernel")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -218,7 +222,7 @@ class Workload:
         self.args, self.rows, self.dev, self.world, self.on_cpu = args, rows, dev, world, on_cpu
         N = args.tasks
         self.bufs, self.views = workloads.synth_task_buffers(rows, N, seed=seed, device=dev)
-        flags = (2 if args.gram32 else 0) | (8 if args.bp2 else 0)
+        flags = (2 if args.gram32 else 0) | (8 if args.bp2 else 0) | (4 if args.xcd else 0)
         self.plan = plan = CompressPlan(rows, N, energy_threshold=args.energy, max_rank=64, center=True, fp16=True,
                                         low_bits=args.bits, rtvq_stages=args.stages, device=dev,
                                         unit_rows=args.unit_rows, flags=flags)
@@ -243,8 +247,9 @@ class Workload:
             self.gather = shard.RaggedGather(plan.small.numel(), "cpu" if on_cpu else dev)
         torch.cuda.synchronize()
         self.placement_ms = []
-        if args.placement_candidates > 1:
-            self.placement_ms = plan.tune_placement(self.table, candidates=args.placement_candidates)
+
+    def tune(self):
+        self.placement_ms = self.plan.tune_placement(self.table, candidates=self.args.placement_candidates)
 
     def _setup_masks(self):
         from svdq_amd.mask_loader import MaskSet
@@ -410,6 +415,13 @@ def main():
 
     ceilings = measured_ceilings(dev) if rank == 0 else None
     wl = Workload(args, rows, dev, 1234 + rank, world, on_cpu)
+    untuned = None
+    if args.placement_candidates > 1 and not on_cpu:      # (gloo rehearsal: several ranks share one card's memory)
+        e0, sc0, kms0 = wl.timed(dist, args.steps, args.warmup)
+        untuned = {"ms_per_step": round(e0 / args.steps * 1e3, 4), "value": round(sc0 / (e0 / args.steps) / 1e6, 1),
+                   "k_basis_project_ms": round(kms0[2], 4) if kms0[2] == kms0[2] else None,
+                   "what": "the same K steps before tune_placement: outputs in the first allocation as it comes"}
+        wl.tune()
     elapsed, total_scalars, kms = wl.timed(dist, args.steps, args.warmup)
     plan = wl.plan
     sm = plan.fetch_small()
@@ -436,6 +448,8 @@ def main():
         del wl, plan, sm
         torch.cuda.empty_cache()
         wlw = Workload(args, rows_all, dev, 1234 + rank, world, on_cpu)
+        if args.placement_candidates > 1 and not on_cpu:
+            wlw.tune()
         e2, sc2, _ = wlw.timed(dist, args.steps, args.warmup)
         weak = {"value": round(sc2 / (e2 / args.steps) / 1e6, 1), "unit": "MParams/s",
                 "ms_per_step": round(e2 / args.steps * 1e3, 4), "what": "one full model per rank (per-GPU work fixed)"}
@@ -463,8 +477,10 @@ def main():
                        "schedule": "6 kernels: gram, reduce, eig, basis_project, reduce, coeff (+ a 4-byte memset)",
                        "gram": "fp32 products" if (args.gram32 or N > 16) else "fp64 MFMA (exact products)",
                        "from_base": args.from_base,
-                       "output_placement": (f"fastest of {len(placement_ms)} candidate allocations for the basis, chosen "
-                                            f"before the timed region: {[round(x, 3) for x in placement_ms]} ms"
+                       "output_placement": (f"CompressPlan.tune_placement, once before the timed region: "
+                                            f"{len(placement_ms) // 2} candidate allocations walked through the "
+                                            f"device's memory regions, pass 2 timed into each basis candidate, then "
+                                            f"each mean candidate: {[round(x, 3) for x in placement_ms]} ms"
                                             if placement_ms else "first allocation as it comes"),
                        "masks": args.masks, "mask_density": mask_density,
                        "sharding": "none" if world == 1 else (
@@ -489,6 +505,8 @@ def main():
                                     if ceilings else None),
             "ms_per_step_incl_small_d2h": round(d2h_ms, 4) if d2h_ms is not None else None,
         }
+        if untuned is not None:
+            out["untuned"] = untuned
         if bgather is not None:
             out["basis_gather"] = bgather
         if weak is not None:

@@ -53,6 +53,7 @@ typedef struct svdq_config {
     int32_t reserved;          /* measurement switches, 0 in production.  bit 0: reverse unit order in pass 2;
                                   bit 1: fp32-product Gram for every N (the round-1 kernel; sigma then only resolves
                                   down to ~3e-4 sigma_0 and smaller ones are treated as null directions);
+                                  bit 2: XCD-chunked unit order (XCD x walks a contiguous eighth of the units; measured: no change);
                                   bit 3: N = 17..20: the two-wave pass 2 instead of the one-wave 4x4-block kernel. */
 } svdq_config;
 

@@ -336,7 +336,7 @@ static int bp_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_d
                                      reinterpret_cast<const int32_t *>(sm + pl->small.r_off),
                                      reinterpret_cast<uint8_t *>(basis), mean,
                                      reinterpret_cast<double *>(ws(workspace, pl->ws_cpart_off)), u0, nu,
-                                     pl->cfg.reserved & 1, idx, base, (hipStream_t)stream);
+                                     pl->cfg.reserved & 5, idx, base, (hipStream_t)stream);
 }
 
 extern "C" int svdq_basis_project_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,

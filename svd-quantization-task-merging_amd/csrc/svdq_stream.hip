@@ -53,6 +53,19 @@
 #define PRAGMA_(x) _Pragma(#x)
 #define UNROLL_N(n) PRAGMA_(unroll n)
 
+// Which work unit a workgroup takes.  Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8),
+// and consecutive units are consecutive row ranges of one tensor.  order bit 2 ("XCD-chunked"): XCD x walks ONE
+// contiguous eighth of the unit list, so the address window its L2 and its translation caches see at any time is an
+// eighth of what the interleaved order gives.  bit 0: reversed unit order (measurement).
+__device__ __forceinline__ int unit_of_block(int b, int n, int order) {
+    int u = b;
+    if (order & 4) {
+        const int q = n >> 3, rem = n & 7, x = b & 7;
+        u = x * q + (x < rem ? x : rem) + (b >> 3);
+    }
+    return (order & 1) ? n - 1 - u : u;
+}
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -637,10 +650,10 @@ __global__ __launch_bounds__(64, (F64 && MODE == 0 && NTP <= 16) ? (NTP <= 8 ? S
                                              double *__restrict__ gram_part, int unit0,
                                              const void *const *__restrict__ aux,
                                              const int32_t *__restrict__ only,
-                                             const void *const *__restrict__ aux2) {
+                                             const void *const *__restrict__ aux2, int order) {
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
-    gram_unit<NTP, MODE, F64>(X, unit0 + (int)blockIdx.x, params, units, ptrs, rows_dev, NT, center, gram_part, aux,
-                              only, aux2);
+    gram_unit<NTP, MODE, F64>(X, unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, order), params, units, ptrs,
+                              rows_dev, NT, center, gram_part, aux, only, aux2);
 }
 
 // ------------------------------------------------------------------------------------ pass 2
@@ -978,7 +991,7 @@ __global__ __launch_bounds__(64) void k_basis_project(
     using out_t = typename OutT<OUT16>::type;
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
     __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];  // +16: dump slot for idle lanes
-    const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    const int uidx = unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, reverse);
     bp_unit<NTP, OUT16, MODE>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis,
                               meanbuf, cpart, aux, aux2);
 }
@@ -1103,7 +1116,7 @@ __global__ __launch_bounds__(128) void k_basis_project2(
     __shared__ __attribute__((aligned(16))) f32x4 SUM[128];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    const int uidx = unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, reverse);
     const SvdqUnit ud = units[uidx];
     const int p = ud.param;
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
@@ -1307,7 +1320,7 @@ __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
     __shared__ float W1[NTP * N1];   // W[task][16 + q]: B operands of the 4x4x1 chain
 
     const int lane = threadIdx.x & 63;
-    const int uidx = unit0 + (reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    const int uidx = unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, reverse);
     const SvdqUnit ud = units[uidx];
     const int p = ud.param;
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
@@ -1603,7 +1616,7 @@ static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *r
     auto ai = (const void *const *)idx, ab = (const void *const *)base;
 #define SVDQ_LAUNCH_GRAM(M, F)                                                                                       \
     hipLaunchKernelGGL((k_gram<NTP, M, F>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, rows_dev, \
-                       pl->n_tasks, center, gram_part, unit0, ai, only, ab)
+                       pl->n_tasks, center, gram_part, unit0, ai, only, ab, pl->cfg.reserved & 4)
     const int mode = (idx ? 1 : 0) | (base ? 2 : 0);
     if (f64) {
         switch (mode) {

@@ -662,7 +662,7 @@ def test_tune_placement_keeps_results(sq, orc):
     plan = CompressPlan(sizes, N, **kw)
     table = plan.pointer_table(vecs)
     times = plan.tune_placement(table, candidates=3, reps=2)
-    assert len(times) == 3 and all(t > 0 for t in times)
+    assert len(times) == 6 and all(t > 0 for t in times)      # three basis candidates, then three mean candidates
     for again in (False, True):
         if again:
             plan.run(table)
