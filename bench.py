@@ -125,19 +125,21 @@ def profiled_traffic(kernel: str, model: str, n_tasks: int):
     return None, None
 
 
-def measured_ceilings(dev):
+def measured_ceilings(dev, walk=True):
     """The box's practical HBM ceilings, measured in the pre-timed section with the library's own plain streaming
     kernels (svdq_hbm_probe: 16 B per lane, 8 loads in flight -- the access shape of the two passes) on 2 GiB
-    buffers (8x the Infinity Cache): read-only, copy (bytes moved both ways) and pass 2's 8 : 5 read : write mix."""
+    buffers (8x the Infinity Cache): read-only, copy (bytes moved both ways) and pass 2's 8 : 5 read : write mix.
+    Copy and mix depend on whether source and destination share a 72 GiB region of HBM: the
+    destination is tried in a few places walked through device memory and the best is quoted (the same-region
+    figure is kept beside it)."""
     from ctypes import c_void_p
     import svdq_amd
     lib = svdq_amd._native.lib()
     nbytes = 1 << 31
     x = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
-    y = torch.empty_like(x)
     st = c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def t(mode, reps=6):
+    def t(mode, y, reps=6):
         for _ in range(2):
             lib.svdq_hbm_probe(mode, c_void_p(x.data_ptr()), c_void_p(y.data_ptr()), nbytes, st)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -147,9 +149,20 @@ def measured_ceilings(dev):
         e1.record()
         e1.synchronize()
         return e0.elapsed_time(e1) / reps * 1e-3
-    out = {"read_GBs": round(nbytes / t(0) / 1e9, 1), "copy_GBs": round(2 * nbytes / t(1) / 1e9, 1),
-           "mix_8r5w_GBs": round(nbytes * 13 / 8 / t(2) / 1e9, 1)}
-    del x, y
+    ys, hold = [torch.empty_like(x)], []
+    free, _ = torch.cuda.mem_get_info(dev)
+    spacer = min(40 << 30, int(free * 0.8) // 4)
+    if walk and spacer >= (8 << 30):
+        for _ in range(3):
+            hold.append(torch.empty(spacer, dtype=torch.uint8, device=dev))
+            ys.append(torch.empty_like(x))
+    copies = [t(1, y) for y in ys]
+    best = ys[min(range(len(ys)), key=lambda i: copies[i])]
+    out = {"read_GBs": round(nbytes / t(0, best) / 1e9, 1), "copy_GBs": round(2 * nbytes / min(copies) / 1e9, 1),
+           "mix_8r5w_GBs": round(nbytes * 13 / 8 / t(2, best) / 1e9, 1),
+           "copy_worst_placement_GBs": round(2 * nbytes / max(copies) / 1e9, 1)}
+    del x, ys, hold, best
+    torch.cuda.empty_cache()
     return out
 
 
@@ -413,8 +426,10 @@ def main():
     mine = shard.partition_lpt(rows_all, world)[rank] if (world > 1 and scaling == "strong") else list(range(len(names)))
     rows = [rows_all[i] for i in mine]
 
-    ceilings = measured_ceilings(dev) if rank == 0 else None
     wl = Workload(args, rows, dev, 1234 + rank, world, on_cpu)
+    # after the inputs exist: the probe walks through device memory and leaves holes in several regions behind, which
+    # later allocations would be scattered over
+    ceilings = measured_ceilings(dev, walk=args.placement_candidates > 1) if rank == 0 else None
     untuned = None
     if args.placement_candidates > 1 and not on_cpu:      # (gloo rehearsal: several ranks share one card's memory)
         e0, sc0, kms0 = wl.timed(dist, args.steps, args.warmup)

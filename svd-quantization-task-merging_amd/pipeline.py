@@ -302,6 +302,8 @@ class CompressPlan:
                 e1.synchronize()
                 return e0.elapsed_time(e1) / reps
 
+            for _ in range(3):                         # clocks and caches settle over a few launches: without this
+                self.basis_project(table, rows_dev)    # the first candidate measures ~0.1-0.25 ms slow
             times = []
             for buf in pool_b:
                 self.basis = buf

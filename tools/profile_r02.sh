@@ -13,8 +13,10 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
 cp "$f" $R/gpurun_out/${tag}_bench_kernel_stats.csv && head -n 12 $R/gpurun_out/${tag}_bench_kernel_stats.csv | cut -c1-200
 grep '^{' $R/gpurun_out/${tag}_prof_bench.log > $R/gpurun_out/${tag}_bench_line.json
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f_$tag -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu $EXTRA > /tmp/pmc_f_$tag.log 2>&1 < /dev/null || { tail -n 5 /tmp/pmc_f_$tag.log; exit 1; }
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w_$tag -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu $EXTRA > /tmp/pmc_w_$tag.log 2>&1 < /dev/null || { tail -n 5 /tmp/pmc_w_$tag.log; exit 1; }
+kt=$(find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1)
+python3 $R/tools/trace_timed_region.py "$kt" 10 $R/gpurun_out/${tag}_bench_timed_region.json
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f_$tag -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --placement-candidates 1 $EXTRA > $R/gpurun_out/${tag}_pmc_f.log 2>&1 < /dev/null || { tail -n 5 $R/gpurun_out/${tag}_pmc_f.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w_$tag -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --placement-candidates 1 $EXTRA > $R/gpurun_out/${tag}_pmc_w.log 2>&1 < /dev/null || { tail -n 5 $R/gpurun_out/${tag}_pmc_w.log; exit 1; }
 ff=$(find /tmp/pmc_f_$tag -name "*counter_collection.csv" | head -1)
 fw=$(find /tmp/pmc_w_$tag -name "*counter_collection.csv" | head -1)
 python3 $R/tools/pmc_traffic.py "$ff" "$fw" $R/gpurun_out/${tag}_pmc_traffic.json
