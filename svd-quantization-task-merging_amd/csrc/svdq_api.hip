@@ -30,11 +30,13 @@ extern "C" int svdq_abi_version(void) { return SVDQ_ABI_VERSION; }
 extern "C" const char *svdq_last_error(void) { return g_err; }
 
 static int32_t auto_unit_rows(int64_t D) {
-    // Measured on MI355X, ViT-L-14 x 8 (bench.py --unit-rows sweep): 4096..8192-row units are best --
-    // smaller units multiply the fp64 partial slots the two small kernels must reduce, larger ones
-    // leave a long tail on the 256 CUs x ~12 resident waves.  Small tensors get >= 4 units when they
-    // have the rows for it, never less than 4 blocks per unit.
-    int64_t ur = 8192;
+    // Measured on MI355X (bench.py --unit-rows sweeps, tools/shard_one.py): for a whole ViT-L-14 / ViT-B-32 model
+    // 4096..8192-row units are equal within noise (smaller ones multiply the fp64 partial slots the two small kernels
+    // must reduce), but one rank's share of the 8-GPU run has only ~4 700 units of 8192 rows for 5 120 resident waves --
+    // a single partial wave, 0.765 ms against 0.699 ms with 4096-row units.  The unit size is a function of the
+    // tensor alone (never of what else is in the plan), so a tensor's artifacts are the same bits in any batch and on
+    // any number of GPUs.  Small tensors get >= 4 units when they have the rows for it, never less than 4 blocks each.
+    int64_t ur = 4096;
     if (D < 4 * ur) ur = svdq_align_up((D + 3) / 4, SVDQ_BLK_ROWS);
     if (ur < 4 * SVDQ_BLK_ROWS) ur = 4 * SVDQ_BLK_ROWS;
     return (int32_t)ur;
