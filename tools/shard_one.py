@@ -38,3 +38,26 @@ for ur in (0, 4096, 2048, 1024, 512):
     print(f"unit_rows {ur or 'auto(8192)':>10}: units {plan.sizes.n_units:6d}  gram {t[0]:.3f}  eig {t[1]:.3f}  "
           f"basis_project {t[2]:.3f}  coeff {t[3]:.3f}  sum {sum(t):.3f} ms", flush=True)
     plan.close()
+
+# the same step as one HIP graph launch (six kernels + a memset captured once): does it close the launch gaps?
+plan = CompressPlan(rows, N, energy_threshold=0.9, max_rank=64, center=True, fp16=True, device=dev)
+table = plan.pointer_table(views)
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    for _ in range(3):
+        plan.run(table)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        plan.run(table)
+torch.cuda.synchronize()
+for name, fn in (("eager", lambda: plan.run(table)), ("graph replay", g.replay)):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name}: {e0.elapsed_time(e1) / 50:.4f} ms per step (50 steps back to back)", flush=True)
