@@ -153,9 +153,12 @@ def measured_ceilings(dev, walk=True):
     free, _ = torch.cuda.mem_get_info(dev)
     spacer = min(40 << 30, int(free * 0.8) // 4)
     if walk and spacer >= (8 << 30):
-        for _ in range(3):
-            hold.append(torch.empty(spacer, dtype=torch.uint8, device=dev))
-            ys.append(torch.empty_like(x))
+        try:
+            for _ in range(3):
+                hold.append(torch.empty(spacer, dtype=torch.uint8, device=dev))
+                ys.append(torch.empty_like(x))
+        except torch.cuda.OutOfMemoryError:
+            del hold[:]
     copies = [t(1, y) for y in ys]
     best = ys[min(range(len(ys)), key=lambda i: copies[i])]
     out = {"read_GBs": round(nbytes / t(0, best) / 1e9, 1), "copy_GBs": round(2 * nbytes / min(copies) / 1e9, 1),

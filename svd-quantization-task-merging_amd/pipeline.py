@@ -284,12 +284,17 @@ class CompressPlan:
             spacer = min(max_spacer_bytes, room // max(candidates - 1, 1))
             spacer = spacer if (spacer >= (1 << 30) and bb + nm >= (1 << 30)) else 0   # small outputs: no walk
             hold, pool_b, pool_m = [], [self.basis], [self.mean]
-            for _ in range(candidates - 1):
-                if spacer:
-                    hold.append(torch.empty(spacer, dtype=torch.uint8, device=dev))
-                pool_b.append(torch.empty(bb, dtype=torch.uint8, device=dev))
-                if nm:
-                    pool_m.append(torch.empty(nm // 4, dtype=torch.float32, device=dev))
+            try:
+                for _ in range(candidates - 1):
+                    if spacer:
+                        hold.append(torch.empty(spacer, dtype=torch.uint8, device=dev))
+                    pool_b.append(torch.empty(bb, dtype=torch.uint8, device=dev))
+                    if nm:
+                        pool_m.append(torch.empty(nm // 4, dtype=torch.float32, device=dev))
+            except torch.cuda.OutOfMemoryError:        # a fuller device than mem_get_info promised: fewer candidates
+                del hold[:]
+                if len(pool_m) > len(pool_b):
+                    pool_m.pop()
 
             def timed() -> float:
                 self._typed = None
