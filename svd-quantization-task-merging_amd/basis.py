@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _native as nat
-from .pipeline import (CompressPlan, basis_dict, compress_batch, prepare_vector, resolve_device)
+from .pipeline import (CompressPlan, basis_dict, compress_batch, prepare_vector, resolve_device, wants_cpu)
 
 
 def stack_and_center(vectors: List[torch.Tensor], center: bool = True
@@ -91,13 +91,17 @@ def construct_basis(deltas: List[torch.Tensor], energy_threshold: float = 0.90, 
                     center: bool = True, device: str = "cpu", use_randomized: bool = False,
                     verbose: bool = True) -> Dict:
     """Reference basis.py:252-409.  Returns {U_high [D,k], U_low [D,r-k], singular_values, k, mean
-    [D,1]|None, energy_retained, D, N}; tensors live on the GPU (fp32, as in the reference before
-    the cli.py:354-361 cast)."""
+    [D,1]|None, energy_retained, D, N}; tensors live on ``device`` (fp32, as in the reference before the
+    cli.py:354-361 cast): zero-copy views of the GPU buffers for a GPU device, copies for ``"cpu"``."""
     if not deltas:
         raise ValueError("Empty delta list")
     plan, sm = _run_single(deltas, energy_threshold, max_rank, center, device, fp16=False)
     out = basis_dict(plan, sm, 0)
-    out["_svdq_plan"] = plan  # keeps the slab alive for the zero-copy views
+    if wants_cpu(device):
+        out = {key: (v.cpu() if isinstance(v, torch.Tensor) else v) for key, v in out.items()}
+        plan.close()
+    else:
+        out["_svdq_plan"] = plan  # keeps the slab alive for the zero-copy views
     if verbose:
         print(f"   SVD basis: D={out['D']} N={out['N']} k={out['k']} energy={out['energy_retained']:.4f}")
     return out

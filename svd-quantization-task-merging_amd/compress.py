@@ -37,20 +37,33 @@ def _project(delta, U_high, U_low, mean):
         return torch.zeros(0, device=out_dev), torch.zeros(0, device=out_dev)
     if (k and U_high.shape[0] != D) or (nl and U_low.shape[0] != D):
         raise ValueError(f"Shape mismatch: basis rows vs delta length {D}")
-    if k + nl > 32:
-        raise ValueError("at most 32 basis columns (tasks) are supported")
     fp16 = (U_high.dtype == torch.float16) if k else (U_low.dtype == torch.float16)
     dt = torch.float16 if fp16 else torch.float32
     uh = U_high.to(device=dev, dtype=dt).contiguous() if k else None
     ul = U_low.to(device=dev, dtype=dt).contiguous() if nl else None
     m = prepare_vector(mean.squeeze() if mean.dim() > 1 else mean, dev) if mean is not None else None
+    if k + nl <= 32:
+        c = _project_cols(lib, dev, uh, ul, fp16, D, k, nl, x, m)
+    else:
+        # the kernel takes up to 32 columns (the path never has more than N <= 32); a caller's own wider basis
+        # (the reference's tests project onto full square bases) goes through in column groups
+        parts = []
+        for u, n in ((uh, k), (ul, nl)):
+            for c0 in range(0, n, 32):
+                cn = min(32, n - c0)
+                parts.append(_project_cols(lib, dev, u[:, c0:c0 + cn].contiguous(), None, fp16, D, cn, 0, x, m))
+        c = torch.cat(parts)
+    c = c.to(out_dev)
+    return c[:k], c[k:]
+
+
+def _project_cols(lib, dev, uh, ul, fp16, D, k, nl, x, m):
     c = torch.empty(k + nl, dtype=torch.float32, device=dev)
     work = torch.empty(int(lib.svdq_project_work_bytes(D, k + nl)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         nat.check(lib.svdq_project(_ptr(uh), _ptr(ul), int(fp16), D, k, nl, _ptr(x), _ptr(m), _ptr(c), _ptr(work),
                                    _stream_ptr()), "svdq_project")
-    c = c.to(out_dev)
-    return c[:k], c[k:]
+    return c
 
 
 def compress_single_task(task_delta: torch.Tensor, U_high: torch.Tensor, U_low: torch.Tensor,

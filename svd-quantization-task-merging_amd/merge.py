@@ -12,7 +12,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _native as nat
-from .pipeline import prepare_vector, resolve_device, _ptr, _stream_ptr
+from .pipeline import prepare_vector, resolve_device, wants_cpu, _ptr, _stream_ptr
 from .rtvq import RTVQQuantizer
 
 
@@ -40,8 +40,9 @@ def dequantize_and_average(compressed_coeffs: Dict[str, Dict], weights: Dict[str
 def reconstruct_from_coefficients(avg_c_high: torch.Tensor, avg_c_low: torch.Tensor, U_high: torch.Tensor,
                                   U_low: torch.Tensor, device: str = "cpu", mean: Optional[torch.Tensor] = None
                                   ) -> torch.Tensor:
-    """Reference merge.py:144-194: U_high c_high + U_low c_low (+ mean); result on the GPU."""
-    return _reconstruct(avg_c_high, avg_c_low, U_high, U_low, mean, 1.0)
+    """Reference merge.py:144-194: U_high c_high + U_low c_low (+ mean); result on ``device`` (computed on the GPU)."""
+    out = _reconstruct(avg_c_high, avg_c_low, U_high, U_low, mean, 1.0)
+    return out.cpu() if wants_cpu(device) else out
 
 
 def _reconstruct(avg_c_high, avg_c_low, U_high, U_low, mean, scale: float) -> torch.Tensor:
@@ -51,8 +52,6 @@ def _reconstruct(avg_c_high, avg_c_low, U_high, U_low, mean, scale: float) -> to
     D = U_high.shape[0] if U_high.dim() == 2 else U_low.shape[0]
     k = U_high.shape[1] if U_high.dim() == 2 else 0
     nl = U_low.shape[1] if U_low.dim() == 2 else 0
-    if k + nl > 32:
-        raise ValueError("at most 32 basis columns (tasks) are supported")
     fp16 = (U_high.dtype == torch.float16) if k else (U_low.dtype == torch.float16)
     dt = torch.float16 if fp16 else torch.float32
     uh = U_high.to(device=dev, dtype=dt).contiguous() if k else None
@@ -65,8 +64,22 @@ def _reconstruct(avg_c_high, avg_c_low, U_high, U_low, mean, scale: float) -> to
     if D == 0:
         return out
     with torch.cuda.device(dev):
-        nat.check(lib.svdq_reconstruct(_ptr(uh), _ptr(ul), int(fp16), D, k, nl, _ptr(coef), _ptr(m), float(scale),
-                                       _ptr(out), _stream_ptr()), "svdq_reconstruct")
+        if k + nl <= 32:
+            nat.check(lib.svdq_reconstruct(_ptr(uh), _ptr(ul), int(fp16), D, k, nl, _ptr(coef), _ptr(m), float(scale),
+                                           _ptr(out), _stream_ptr()), "svdq_reconstruct")
+        else:
+            # wider than the path ever is (N <= 32): column groups, each adding onto the running sum through the
+            # kernel's `mean` input; the scale goes on last
+            groups = [(u[:, c0:c0 + 32].contiguous(), off + c0, min(32, n - c0))
+                      for u, n, off in ((uh, k, 0), (ul, nl, k)) if n for c0 in range(0, n, 32)]
+            acc, dst = m, (out, torch.empty_like(out))     # input and output of a launch never alias
+            for i, (u, c0, cn) in enumerate(groups):
+                last = i == len(groups) - 1
+                nat.check(lib.svdq_reconstruct(_ptr(u), _ptr(None), int(fp16), D, cn, 0, _ptr(coef[c0:c0 + cn]),
+                                               _ptr(acc), float(scale) if last else 1.0, _ptr(dst[i % 2]),
+                                               _stream_ptr()), "svdq_reconstruct")
+                acc = dst[i % 2]
+            out = acc
     return out
 
 
@@ -90,10 +103,12 @@ def merge_parameter(param_name: str, compressed_params: Dict[str, Dict], basis: 
             if ch is not None:
                 merged_unmasked = _reconstruct(ch, cl, bu["U_high"], bu["U_low"], bu.get("mean"), noise_shrink)
     if mask is not None and merged_masked is not None:
-        return reconstruct_from_masked(merged_masked, merged_unmasked, mask, original_shape)
-    if merged_masked is not None:
-        return merged_masked.view(original_shape)
-    return torch.zeros(original_shape, device=dev)
+        res = reconstruct_from_masked(merged_masked, merged_unmasked, mask, original_shape)
+    elif merged_masked is not None:
+        res = merged_masked.view(original_shape)
+    else:
+        res = torch.zeros(original_shape, device=dev)
+    return res.cpu() if wants_cpu(device) else res      # the reference returns on `device` (default "cpu")
 
 
 def merge_all_parameters(compressed_all: Dict[str, Dict[str, Dict]], bases: Dict[str, Dict],

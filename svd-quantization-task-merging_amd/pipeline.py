@@ -33,6 +33,13 @@ def resolve_device(device) -> torch.device:
     return dev
 
 
+def wants_cpu(device) -> bool:
+    """True when the caller asked for results on the CPU (the reference's default ``device="cpu"``).  The arithmetic
+    runs on the GPU either way; such a caller gets its result tensors copied back, as the reference would return them."""
+    d = torch.device(device) if not isinstance(device, torch.device) else device
+    return d.type == "cpu"
+
+
 def prepare_vector(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
     """fp32, contiguous, flat, on ``dev``, 16-byte aligned (the only input contract of the ABI).  A tensor that
     already is all of that comes back as it is (a model's worth of task tensors makes this the hot host call)."""
