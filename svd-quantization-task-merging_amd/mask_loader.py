@@ -276,11 +276,10 @@ def combine_masks(task_masks: Dict[str, Dict[str, torch.Tensor]], strategy: str 
         ms = MaskSet([per_param[n][0].numel() for n in group], dev_in if dev_in.type == "cuda" else "cuda")
         outs, _ = ms.combine([per_param[n] for n in group], strategy)
         for n, o in zip(group, outs):
-            combined[n] = o.view(torch.bool).view(shape0[n]).to(device if torch.device(device).type == "cuda"
-                                                                     else per_param[n][0].device)
+            combined[n] = o.view(torch.bool).view(shape0[n]).to(device)      # the reference moves every mask to `device`
     for n, lst in per_param.items():          # zero-sized parameters
         if lst and lst[0].numel() == 0:
-            combined[n] = torch.zeros(lst[0].shape, dtype=torch.bool, device=lst[0].device)
+            combined[n] = torch.zeros(lst[0].shape, dtype=torch.bool, device=device)
     if verbose:
         print(f"   combined masks for {len(combined)} parameters with strategy '{strategy}'")
     return combined
