@@ -3,9 +3,19 @@ import numpy as np
 import pytest
 import torch
 
-import svdq_amd  # noqa: F401  (registers the operators)
+import svdq_amd  # noqa: F401  (registers the operators when the libraries are already built)
 
 OPS = ("rtvq_quantize", "rtvq_dequantize", "mask_combine", "mask_select", "compress", "ingest", "task_gram")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _ops_loaded():
+    """A fresh checkout has no libraries when pytest imports this module: build them, then register the operators."""
+    import os
+    from svdq_amd import torch_ops, _native
+    if not (os.path.exists(_native.LIB_PATH) and os.path.exists(torch_ops.OPS_LIB_PATH)):
+        _native.build()
+    torch_ops.load()
 
 
 def test_ops_are_registered_natively():
