@@ -29,6 +29,9 @@
 #include <hip/hip_fp16.h>
 
 #define XS SVDQ_XS
+#ifndef SVDQ_EXP_ULOW_SHIFT
+#define SVDQ_EXP_ULOW_SHIFT 0   // experiment builds only (tools/placement_probe7.py): U_low written this many bytes further
+#endif
 #ifndef SVDQ_UNROLL_BP
 #define SVDQ_UNROLL_BP 8
 #endif
@@ -779,7 +782,7 @@ __device__ __forceinline__ void bp_unit(
 
     uint8_t *slab = basis + params[p].slab_off;
     uint8_t *gUh = slab;
-    uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
+    uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256) + SVDQ_EXP_ULOW_SHIFT;
     float *gmean = (center && meanbuf) ? meanbuf + params[p].mean_off : nullptr;
 
     double caccd[NCB][4];
@@ -1156,7 +1159,7 @@ __global__ __launch_bounds__(128) void k_basis_project2(
 
     uint8_t *slab = basis + params[p].slab_off;
     uint8_t *gUh = slab;
-    uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
+    uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256) + SVDQ_EXP_ULOW_SHIFT;
     float *gmean = (center && meanbuf) ? meanbuf + params[p].mean_off : nullptr;
 
     double caccd[2][4];
@@ -1380,7 +1383,7 @@ __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
     }
     uint8_t *slab = basis + params[p].slab_off;
     uint8_t *gUh = slab;
-    uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
+    uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256) + SVDQ_EXP_ULOW_SHIFT;
     float *gmean = (center && meanbuf) ? meanbuf + params[p].mean_off : nullptr;
 
     double caccd[2][4];          // columns 0..15 x tasks (two 16-task blocks): fp32 inside a half block, fp64 across
