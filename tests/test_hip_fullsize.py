@@ -272,3 +272,58 @@ def test_config5_vitl14_x20_mixed_widths_cluster_merge():
         n2 += 1
     assert n2 >= 20, n2
     assert eo2 ** 0.5 <= 1.3 * er2 ** 0.5, (eo2 ** 0.5, er2 ** 0.5)
+
+
+def test_single_tensor_beyond_2_pow_30_rows():
+    """Maximum sizes: one parameter of 2^30 + 12 345 rows (4.3 GB per task tensor, byte offsets past 2^32 in every
+    input, in the mean and in the basis slab), N = 3, ragged tail.  Checked at the FAR END of the tensor, where a 32-bit
+    offset anywhere in the kernels would show: mean, and task rows rebuilt from the fp16 basis and the fp32
+    coefficients of the same run; singular values against a fp64 Gram accumulated by torch in chunks."""
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    D, N = (1 << 30) + 12345, 3
+    g = torch.Generator(device=dev).manual_seed(11)
+    shared = torch.randn(D, device=dev, generator=g)
+    vecs = []
+    for t in range(N):
+        v = torch.randn(D, device=dev, generator=g)
+        v.mul_(0.3).add_(shared, alpha=0.5 + 0.25 * t)
+        vecs.append(v)
+    del shared
+    plan = CompressPlan([D], N, energy_threshold=0.9, max_rank=None, center=True, fp16=True, low_bits=4, rtvq_stages=2,
+                        device=dev)
+    plan.run(plan.pointer_table([vecs]))
+    sm = plan.fetch_small()
+    k, r = int(sm.k[0]), int(sm.r[0])
+    assert int(sm.rows[0]) == D and r == N and 1 <= k <= r
+    # fp64 Gram of the centred columns, in chunks
+    G = torch.zeros(N, N, dtype=torch.float64, device=dev)
+    step = 1 << 26
+    for a in range(0, D, step):
+        X = torch.stack([v[a:a + step] for v in vecs], dim=1).double()
+        X -= X.mean(dim=1, keepdim=True)
+        G += X.T @ X
+        del X
+    lam = torch.linalg.eigvalsh(G).flip(0).clamp_min(0).sqrt().cpu().numpy()
+    np.testing.assert_allclose(sm.sigma[0, :N - 1], lam[:N - 1], rtol=2e-5)       # the last one is the centring null direction
+    assert sm.sigma[0, N - 1] <= 1e-5 * sm.sigma[0, 0]
+    U_high, U_low, mean = plan.basis_tensors(0, k, r, D)
+    tail = slice(D - 5000, D)
+    Xt = torch.stack([v[tail] for v in vecs], dim=1)
+    mt = Xt.mean(dim=1, keepdim=True)
+    assert torch.allclose(mean[tail], mt, rtol=1e-5, atol=1e-6)
+    Ut = torch.cat([U_high[tail], U_low[tail]], dim=1).float()
+    coef = torch.from_numpy(sm.coef[0, :N, :r].copy()).to(dev)                    # c[t][i]
+    rec = Ut @ coef.T + mt                                                        # [rows, N]
+    scale = float(Xt.abs().max())
+    assert float((rec - Xt).abs().max()) < 2e-3 * scale                           # fp16 basis rounding
+    # the same at the first rows and across the 2^32-byte boundary of the inputs (row 2^30).  Row 0 itself is left out:
+    # it carries the spike of the completion column (the null direction centring creates), whose other entries
+    # (~1/D) are below fp16 at this size, so the fp16 column is e_0 and its coefficient is the centred row 0 itself --
+    # one element of 2^30 where the rebuilt value is off by |Tc[0][t]| (DESIGN.md, "null directions")
+    for lo in (1, (1 << 30) - 2500):
+        sl = slice(lo, lo + 5000)
+        Xs = torch.stack([v[sl] for v in vecs], dim=1)
+        ms = Xs.mean(dim=1, keepdim=True)
+        Us = torch.cat([U_high[sl], U_low[sl]], dim=1).float()
+        assert float((Us @ coef.T + ms - Xs).abs().max()) < 2e-3 * scale
