@@ -327,3 +327,38 @@ def test_single_tensor_beyond_2_pow_30_rows():
         ms = Xs.mean(dim=1, keepdim=True)
         Us = torch.cat([U_high[sl], U_low[sl]], dim=1).float()
         assert float((Us @ coef.T + ms - Xs).abs().max()) < 2e-3 * scale
+
+
+def test_quantizer_beyond_2_pow_31_elements():
+    """Maximum sizes for the standalone quantizer: 2^31 + 5 elements (code offsets past 2^31, input byte offsets past
+    2^33).  Every stage is restated with torch's own fp32 elementwise kernels (separately rounded multiply and add,
+    round-half-even, clamp -- rtvq.py:4-27, 29-36, 52-79) and compared bit for bit over the WHOLE tensor."""
+    from svdq_amd.rtvq import _quantize_device
+    dev = torch.device("cuda", 0)
+    n, bits, stages = (1 << 31) + 5, 4, 2
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = torch.empty(n, dtype=torch.float32, device=dev)
+    half = n // 2
+    torch.randn(half, generator=g, device=dev, out=x[:half])
+    torch.randn(n - half, generator=g, device=dev, out=x[half:])
+    x.mul_(0.02)
+    x[-1] = 0.25                  # the maximum sits on the very last element
+    codes, scale, zp, rnorm = _quantize_device(x, bits, stages)
+    torch.cuda.synchronize()
+    assert codes.shape == (stages, n)
+    resid = x
+    levels = float(2 ** bits - 1)
+    for s in range(stages):
+        mn, mx = resid.min(), resid.max()
+        sc = torch.tensor(levels, device=dev) / (mx - mn)
+        z = -1 * torch.round(sc * mn)
+        assert sc.item() == scale[s].item() and z.item() == zp[s].item(), (s, sc.item(), scale[s].item())
+        assert abs(float(rnorm[s]) - float(torch.linalg.vector_norm(resid.double()))) <= 1e-5 * float(rnorm[s])
+        step = 1 << 28
+        nxt = torch.empty_like(resid)
+        for a in range(0, n, step):
+            r = resid[a:a + step]
+            q = torch.clamp(torch.round(sc * r + z), 0, levels)
+            assert torch.equal(q.to(torch.uint8), codes[s, a:a + step]), (s, a)
+            nxt[a:a + step] = r - (q - z) / sc
+        resid = nxt
