@@ -362,3 +362,30 @@ def test_quantizer_beyond_2_pow_31_elements():
             assert torch.equal(q.to(torch.uint8), codes[s, a:a + step]), (s, a)
             nxt[a:a + step] = r - (q - z) / sc
         resid = nxt
+
+
+def test_mask_apply_beyond_2_pow_31_elements():
+    """Maximum sizes for the mask operators: apply_mask_to_tensor / get_unmasked_portion on 2^31 + 9 elements
+    (order-preserving compaction, mask_loader.py:651-709), against torch's boolean indexing done in chunks."""
+    import svdq_amd as sq
+    dev = torch.device("cuda", 0)
+    n = (1 << 31) + 9
+    g = torch.Generator(device=dev).manual_seed(31)
+    x = torch.empty(n, dtype=torch.float32, device=dev)
+    m = torch.empty(n, dtype=torch.bool, device=dev)
+    step = 1 << 29
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        torch.randn(b - a, generator=g, device=dev, out=x[a:b])
+        m[a:b] = torch.rand(b - a, generator=g, device=dev) < 0.3
+    m[-1] = True
+    for invert, fn in ((False, sq.apply_mask_to_tensor), (True, sq.get_unmasked_portion)):
+        got = fn(x, m)
+        pos = 0
+        for a in range(0, n, step):
+            b = min(n, a + step)
+            want = x[a:b][~m[a:b] if invert else m[a:b]]
+            assert torch.equal(got[pos:pos + want.numel()], want), (invert, a)
+            pos += want.numel()
+        assert pos == got.numel()
+        del got
