@@ -338,20 +338,24 @@ class Workload:
             if self.on_cpu:       # gloo rehearsal: collectives run on host tensors
                 self.small_host.copy_(plan.small)
                 self.gather.run(self.small_host)
-            else:
-                self.gather.run(plan.small)
+            else:      # pipelined: the exchange of this step travels while the next step computes (shard.RaggedGather)
+                self.gather.run(plan.small, overlap=True)
 
     def timed(self, dist, steps, warmup):
         """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
         for _ in range(warmup):
             self.step()
+        if self.gather is not None:
+            self.gather.finish()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for s in range(steps):
             self.step(ev[s] if self.plain else None)
+        if self.gather is not None:
+            self.gather.finish()          # every exchange of the timed steps has completed before the clock stops
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

@@ -36,7 +36,13 @@ class RaggedGather:
     Step time (``run``): one device-side copy into the send slot and ONE ``all_gather_into_tensor`` -- no size
     exchange, no allocation, no host synchronisation, so it can sit inside a timed (or graph-captured) region.
     ``views()`` returns rank r's bytes as a slice of the receive buffer (valid after the collective has run on
-    the stream)."""
+    the stream).
+
+    ``run(buf, overlap=True)`` is the pipelined form: the collective is launched asynchronously on one of TWO
+    send / receive buffer sets and the caller's stream does not wait for it, so the next step's kernels run while the
+    small artifacts of this step travel; a set is waited for only when it comes up for reuse two steps later (a
+    stream-level wait, the host never blocks).  ``finish()`` makes the caller's stream wait for everything in flight;
+    ``views()`` then refers to the most recent step."""
 
     def __init__(self, nbytes_local: int, device, group=None, align: int = 256):
         import torch.distributed as dist
@@ -48,16 +54,38 @@ class RaggedGather:
         dist.all_gather(sizes, n, group=group)                       # the only size exchange, at plan time
         self.sizes = [int(s.item()) for s in sizes]
         self.stride = (max(self.sizes) + align - 1) // align * align
-        self.send = torch.zeros(max(self.stride, 1), dtype=torch.uint8, device=device)
-        self.recv = torch.empty(max(self.stride, 1) * self.world, dtype=torch.uint8, device=device)
+        self._sets = [(torch.zeros(max(self.stride, 1), dtype=torch.uint8, device=device),
+                       torch.empty(max(self.stride, 1) * self.world, dtype=torch.uint8, device=device))]
+        self._work = [None]
+        self._cur = 0
+        self._device = device
+        self.send, self.recv = self._sets[0]
 
-    def run(self, buf: torch.Tensor) -> torch.Tensor:
+    def run(self, buf: torch.Tensor, overlap: bool = False) -> torch.Tensor:
         import torch.distributed as dist
         if buf.numel() != self.nbytes:
             raise ValueError(f"buffer has {buf.numel()} bytes, the gather was planned for {self.nbytes}")
+        if overlap:
+            if len(self._sets) == 1:                                  # the second set, on first use
+                self._sets.append((torch.zeros_like(self._sets[0][0]), torch.empty_like(self._sets[0][1])))
+                self._work.append(None)
+            self._cur = (self._cur + 1) % 2
+            if self._work[self._cur] is not None:                     # its previous collective (two steps ago)
+                self._work[self._cur].wait()
+            self.send, self.recv = self._sets[self._cur]
         self.send[:self.nbytes].copy_(buf.view(torch.uint8).reshape(-1), non_blocking=True)
-        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        if overlap:
+            self._work[self._cur] = dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=True)
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         return self.recv
+
+    def finish(self):
+        """The caller's stream waits for every collective still in flight (no-op without ``overlap``)."""
+        for i, w in enumerate(self._work):
+            if w is not None:
+                w.wait()
+                self._work[i] = None
 
     def views(self) -> List[torch.Tensor]:
         return [self.recv[r * self.stride:r * self.stride + self.sizes[r]] for r in range(self.world)]

@@ -62,6 +62,13 @@ def _worker(rank, world, port, q):
             for r, buf in enumerate(rg.views()):
                 want = torch.tensor([(i % 251 + step) % 256 for i in parts[r] for _ in range(3)], dtype=torch.uint8)
                 assert torch.equal(buf, want), (step, r)
+        # the pipelined form: asynchronous collectives on two alternating buffer sets, waited for on reuse / finish()
+        for step in range(5):
+            rg.run((payload + 10 + step).to(torch.uint8), overlap=True)
+        rg.finish()
+        for r, buf in enumerate(rg.views()):
+            want = torch.tensor([(i % 251 + 14) % 256 for i in parts[r] for _ in range(3)], dtype=torch.uint8)
+            assert torch.equal(buf, want), ("overlap", r)
         try:
             rg.run(payload[:-1])
             raise AssertionError("a buffer of another length must be refused")
