@@ -1,5 +1,6 @@
 """
-End-to-end test of the reference-shaped driver (svdq_amd.cli, scripts/run_svd_hybrid.py, scripts/reload_svd_hybrid.py)
+End-to-end test of the reference-shaped driver (svdq_amd.cli, scripts/run_svd_hybrid.py, scripts/reload_svd_hybrid.py,
+scripts/load_and_merge.py)
 on synthetic checkpoints written to disk: flags -> config -> the whole pipeline on the GPU -> the reference's output
 files -> reload from artifacts.  Also pins compute_compression_statistics to the reference's numbers.
 """
@@ -97,6 +98,18 @@ def test_cli_end_to_end(sq, tmp_path, weighting, with_masks):
                              str(art), "--base-model-path", str(tmp_path / "base.pt"), "--verify",
                              str(out / "merged_state_dict.pt")], capture_output=True, text=True, timeout=300)
         assert rc.returncode == 0 and "MATCH" in rc.stdout, rc.stdout + rc.stderr
+        # the reference's top-level load_and_merge.py: the same from its four flags (default --device cpu: results on
+        # the host), written to --output-path
+        outp = tmp_path / "merged_again.pt"
+        rc = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "load_and_merge.py"), "--artifact-dir",
+                             str(art), "--base-model-path", str(tmp_path / "base.pt"), "--output-path", str(outp)],
+                            capture_output=True, text=True, timeout=300)
+        assert rc.returncode == 0, rc.stdout + rc.stderr
+        again = torch.load(outp, map_location="cpu", weights_only=True)
+        saved = torch.load(out / "merged_state_dict.pt", map_location="cpu", weights_only=True)
+        assert set(again) == set(saved)
+        for key, v in saved.items():
+            assert torch.allclose(again[key].float(), v.float(), atol=1e-5), key
 
 
 def test_cli_argument_errors(sq):
