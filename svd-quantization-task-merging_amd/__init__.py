@@ -25,7 +25,7 @@ from .merge import (dequantize_and_average, reconstruct_from_coefficients, merge
                     apply_merged_deltas, merge_with_clustering)
 from .weighting import (load_performance_metrics, compute_uniform_weights, compute_performance_weights,
                         compute_cluster_weights, compute_weights, apply_weights_to_tensors, get_weight_statistics)
-from .clustering import (cluster_tasks, task_gram, cluster_from_gram, cluster_statistics_from_gram,
+from .clustering import (cluster_tasks, task_gram, cluster_from_gram, cluster_statistics_from_gram, flatten_task_vectors,
                          get_cluster_members, compute_cluster_statistics, merge_by_cluster, merge_cluster_results,
                          compute_kmeans_clustering, compute_hierarchical_clustering)
 from .diagnostics import (compute_reconstruction_error, compute_parameter_diagnostics, compute_all_diagnostics,
@@ -43,7 +43,8 @@ from .ingest import ElementwiseBatch, ingest_state_dicts, quantize_state_dict, d
 from .driver import build_bases, run_basis_and_compress, run_basis_and_compress_from_checkpoints
 from .pipeline import CompressPlan, compress_batch
 from . import quantization_utils
-from .quantization_utils import absmax_quantization, dequantize_absmax
+from .quantization_utils import (absmax_quantization, dequantize_absmax, qunatization_error_check,
+                                 quantization_error_check_asymmetric)
 from . import cli
 from . import torch_ops   # registers torch.ops.svdq.*
 

@@ -61,6 +61,22 @@ def task_gram(task_vectors: Dict[str, Dict[str, torch.Tensor]], device="cuda", *
     return out, tasks
 
 
+def flatten_task_vectors(task_vectors: Dict[str, Dict[str, torch.Tensor]]) -> Tuple[np.ndarray, List[str]]:
+    """Reference clustering.py:55-120: the [N, sum D] feature matrix (rows = tasks in sorted-name order, parameters in
+    sorted-name order, zeros where a task lacks a parameter) and the task names.  Kept for API compatibility only:
+    nothing in this package needs the matrix -- ``cluster_tasks`` works from the N x N Gram (``task_gram``), which is
+    all the clustering ever uses of it -- and at ViT-L-14 x 20 it is 24 GB of host memory."""
+    names = sorted(task_vectors.keys())
+    params = sorted({p for tv in task_vectors.values() for p in tv})
+    shape_of = {p: next(tv[p] for tv in task_vectors.values() if p in tv) for p in params}
+    rows = []
+    for t in names:
+        tv = task_vectors[t]
+        parts = [(tv[p] if p in tv else torch.zeros_like(shape_of[p])).flatten() for p in params]
+        rows.append(torch.cat(parts, dim=0).cpu().numpy())
+    return np.stack(rows, axis=0), names
+
+
 def gram_embedding(G: np.ndarray) -> np.ndarray:
     """Rows e_i in R^N with e_i . e_j = G_ij (eigen-decomposition, negative round-off clipped)."""
     lam, Q = np.linalg.eigh((G + G.T) * 0.5)

@@ -140,5 +140,23 @@ def test_quantization_utils_absmax(sq):                             # test_quant
     assert qa.dtype == torch.uint8
     rec = qu.dequantize_asymmetric(qa, sa, za)
     assert float((rec.cpu() - X).abs().max()) <= 0.5 / float(sa) * (1 + 1e-5)
-    with pytest.raises(NotImplementedError):
-        qu.asymmetric_quantization(X, qbit=16)
+    # qbit = 16: int16 codes as the reference's cast leaves them (65 535 levels, values above 32 767 wrap negative)
+    q16a, s16a, z16a = qu.asymmetric_quantization(X, qbit=16)
+    assert q16a.dtype == torch.int16 and q16a.shape == X.shape
+    lv = torch.where(q16a.cpu() < 0, q16a.cpu().to(torch.int32) + 65536, q16a.cpu().to(torch.int32))
+    assert int(lv.min()) == 0 and int(lv.max()) == 65535
+    # the two print-only checkers (quantization_utils.py:175-212), original names
+    sd = {"w": X.clone(), "keep": torch.arange(4.0)}
+    capsys_out = []
+    import io, contextlib
+    for fn, qd in ((qu.qunatization_error_check, {"w": q8.cpu(), "w_qscale": s8.cpu(), "keep": sd["keep"]}),
+                   (qu.quantization_error_check_asymmetric,
+                    {"w": qa.cpu(), "w_qscale": sa.cpu(), "w_qzeropoint": za.cpu(), "keep": sd["keep"]})):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            fn(sd, qd)
+        assert buf.getvalue().startswith("accumuated Quantized error:")
+        capsys_out.append(float(buf.getvalue().split("error:")[1].strip().replace("tensor(", "").rstrip(")")))
+    # 100 elements x at most half a level each (the absmax checker divides by the scale -- the true inverse, unlike
+    # the reference's dequantize_absmax, Q5)
+    assert 0.0 < capsys_out[1] < 1.0 and 0.0 < capsys_out[0] < 1.5
