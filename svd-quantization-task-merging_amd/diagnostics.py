@@ -198,12 +198,22 @@ def compute_compression_statistics(task_vectors: Dict[str, Dict[str, torch.Tenso
                     "num_stages": stages}}
 
 
-def print_detailed_compression_report(stats: Dict, config=None) -> None:
-    """Short form of diagnostics.py:569-708 (the numbers, not the tutorial text)."""
-    s = stats["summary"]
+def print_detailed_compression_report(compression_stats: Dict, config=None, top_n_params: int = 5) -> None:
+    """Short form of diagnostics.py:569-708: the numbers of the reference's report (overall sizes and shares, then
+    the ``top_n_params`` largest parameters with their own breakdown), not its tutorial text and box drawing."""
+    s = compression_stats["summary"]
     print(f"   compression: {s['original_size_mb']:.2f} MB -> {s['compressed_size_mb']:.2f} MB "
           f"({s['overall_compression_ratio']:.2f}x; bases {100 * s['bases_fraction']:.1f} %, fp16 "
           f"{100 * s['fp16_fraction']:.1f} %, RTVQ {100 * s['rtvq_fraction']:.1f} %)")
+    per_param = compression_stats.get("per_parameter") or {}
+    top = sorted(per_param.items(), key=lambda kv: kv[1].get("original_bytes", 0), reverse=True)[:max(int(top_n_params), 0)]
+    bits = getattr(config, "svd_low_bits", None)
+    for name, ps in top:
+        shown = name[:50] + "..." if len(name) > 50 else name
+        print(f"      {shown}: {ps.get('original_bytes', 0) / 1024:.2f} KB -> {ps.get('compressed_bytes', 0) / 1024:.2f} KB "
+              f"({ps.get('compression_ratio', 0):.2f}x), k = {ps.get('k', 0)}, D = {ps.get('D', 0):,}; fp16 "
+              f"{ps.get('fp16_high_energy_bytes', 0) / 1024:.2f} KB, "
+              f"{str(bits) + '-bit ' if bits is not None else ''}RTVQ {ps.get('rtvq_low_energy_bytes', 0) / 1024:.2f} KB")
 
 
 def print_diagnostics_summary(diagnostics: Dict) -> None:

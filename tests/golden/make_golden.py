@@ -850,6 +850,47 @@ def gen_rank():
     save("rank_kats.npz", **out)
 
 
+def gen_api():
+    """api_signatures.json: the public callables of the reference's in-scope modules -- names, argument names and
+    defaults as text (inspect.signature of the imported reference; class methods as Class.method).  Data about the
+    interface, not source: tests/test_abi_cpu.py checks that this package offers every one of them with the same
+    leading arguments."""
+    import inspect
+    import task_vectors as ref_tv
+    from src.svd_hybrid import storage as ref_storage, task_vector_loader as ref_tvl, reload as ref_reload
+
+    def sig(fn):
+        out = []
+        for name, prm in inspect.signature(fn).parameters.items():
+            if prm.kind in (prm.VAR_POSITIONAL, prm.VAR_KEYWORD):
+                out.append(("*" if prm.kind == prm.VAR_POSITIONAL else "**") + name)
+            else:
+                out.append(name if prm.default is prm.empty else f"{name}={prm.default!r}")
+        return out
+
+    mods = {"basis": ref_basis, "compress": ref_compress, "rtvq": ref_rtvq, "mask_loader": ref_masks, "merge": ref_merge,
+            "diagnostics": ref_diag, "storage": ref_storage, "weighting": ref_weighting, "clustering": ref_cluster,
+            "task_vector_loader": ref_tvl, "reload": ref_reload, "quantization_utils": ref_qutils,
+            "task_vectors": ref_tv}
+    api = {}
+    for mname, mod in mods.items():
+        entry = {}
+        for name, obj in vars(mod).items():
+            if name.startswith("_") or getattr(obj, "__module__", None) != mod.__name__ or name == "main":
+                continue
+            if inspect.isfunction(obj):
+                entry[name] = sig(obj)
+            elif inspect.isclass(obj):
+                entry[name] = sig(obj.__init__)[1:]
+                for meth, mobj in vars(obj).items():
+                    if inspect.isfunction(mobj) and not meth.startswith("_"):
+                        entry[f"{name}.{meth}"] = sig(mobj)[1:]
+        api[mname] = entry
+    with open(os.path.join(HERE, "api_signatures.json"), "w") as f:
+        json.dump(api, f, indent=1, sort_keys=True)
+    print("api_signatures.json:", {m: len(v) for m, v in api.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate only the named families, e.g. `make_golden.py cluster`
         for fam in sys.argv[1:]:
@@ -867,3 +908,4 @@ if __name__ == "__main__":
     gen_storage()
     gen_cluster()
     gen_tvq()
+    gen_api()

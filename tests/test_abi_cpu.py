@@ -155,3 +155,47 @@ def test_main_dispatcher_unimplemented_methods():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "main.py"), "--method", "nope"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
+
+
+def test_every_public_callable_of_the_reference_modules_is_offered(sq):
+    """tests/golden/api_signatures.json was written by make_golden.py from the imported reference: every public
+    function / class / method of its in-scope modules, with argument names and defaults.  This package must offer each
+    one under the same name with the same leading arguments and defaults (it may add trailing ones)."""
+    import json
+    api = json.load(open(os.path.join(ROOT, "tests", "golden", "api_signatures.json")))
+    home = {"reload": "storage"}                       # reload.py's two functions live in storage.py here
+
+    def sig(fn, drop_self=False):
+        out = []
+        for name, prm in list(inspect.signature(fn).parameters.items())[1 if drop_self else 0:]:
+            if prm.kind in (prm.VAR_POSITIONAL, prm.VAR_KEYWORD):
+                out.append(("*" if prm.kind == prm.VAR_POSITIONAL else "**") + name)
+            else:
+                out.append(name if prm.default is prm.empty else f"{name}={prm.default!r}")
+        return out
+
+    import importlib
+    problems = []
+    for mod_name, entries in api.items():
+        mod = importlib.import_module(f"svdq_amd.{home.get(mod_name, mod_name)}")
+        for name, want in entries.items():
+            cls, _, meth = name.partition(".")
+            obj = getattr(mod, cls, None)
+            if obj is None:
+                problems.append(f"{mod_name}.{name}: missing")
+                continue
+            if meth:
+                obj = getattr(obj, meth, None)
+                if obj is None:
+                    problems.append(f"{mod_name}.{name}: missing")
+                    continue
+                got = sig(obj, drop_self=True)
+            elif inspect.isclass(obj):
+                got = sig(obj.__init__, drop_self=True)
+            else:
+                got = sig(obj)
+            # an optional argument where the reference has a required one is a superset (reload's output_path)
+            same = len(got) >= len(want) and all(g == w or g.split("=")[0] == w for g, w in zip(got, want))
+            if not same:
+                problems.append(f"{mod_name}.{name}: reference {want}, here {got}")
+    assert not problems, "\n".join(problems)
