@@ -46,6 +46,7 @@ from . import quantization_utils
 from .quantization_utils import (absmax_quantization, dequantize_absmax, qunatization_error_check,
                                  quantization_error_check_asymmetric)
 from . import cli
+from . import hydra_entry
 from . import torch_ops   # registers torch.ops.svdq.*
 
 # aliases named by BASELINE.json's north_star (quantization_utils.py)

@@ -199,3 +199,15 @@ def test_every_public_callable_of_the_reference_modules_is_offered(sq):
             if not same:
                 problems.append(f"{mod_name}.{name}: reference {want}, here {got}")
     assert not problems, "\n".join(problems)
+
+
+def test_hydra_style_configuration(sq):
+    """hydra_entry.py:66-101: nested configuration -> SVDHybridConfig with the entry point's own defaults."""
+    from svdq_amd import hydra_entry
+    cfg = hydra_entry.config_from_hydra({"tasks": ["Cars", "DTD"], "checkpoint_dir": "ck", "method": {"svd_low_bits": 2}})
+    assert cfg.tasks == ["Cars", "DTD"] and cfg.checkpoint_dir == "ck" and cfg.svd_low_bits == 2
+    assert cfg.svd_energy_threshold == 0.90 and cfg.svd_max_rank == 128 and cfg.svd_weighting_temperature == 1.0
+    assert cfg.output_dir == "./svd_hybrid_output" and cfg.device == "cuda"
+    assert hydra_entry.config_from_hydra({"method": "svd_hybrid"}).svd_rtvq_stages == 2
+    with pytest.raises(ValueError):
+        hydra_entry.config_from_hydra({"method": {"svd_mask_strategy": "nope"}})
