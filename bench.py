@@ -15,9 +15,10 @@ N > 1: one rank per GPU over RCCL.  `python bench.py --gpus N` started WITHOUT a
 (a parent process that never touches the GPU runs `python -m torch.distributed.run ... bench.py`); started by
 torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.  Parameter tensors are independent
 units: ranks take disjoint tensors, no data-path collective; the packed small artifacts (KB..MB) are all-gathered at the
-end of every step, inside the timed region (one all_gather_into_tensor into a preallocated buffer; sizes were
-exchanged at plan time); the fp16 bases stay on their owning GPU and the cost of gathering them is measured and
-reported separately.
+end of every step, inside the timed region (one asynchronous all_gather_into_tensor into one of two preallocated buffer
+sets, so the exchange travels behind the next step's compute; sizes were exchanged at plan time; every exchange has
+completed before the clock stops); the fp16 bases stay on their owning GPU and the cost of gathering them is measured
+and reported separately.
   "strong" (default for N > 1, BASELINE configs[3]): ONE model's tensors LPT-partitioned over the ranks.
   "weak": every rank processes one full model's worth of tensors (also measured and printed as `weak` when N > 1).
 
@@ -26,6 +27,9 @@ The JSON line also carries
                 (read every delta once, write U fp16, write mean fp32) / its HIP-event time; the box's measured copy /
                 read ceilings; the fraction any two-pass schedule could reach at that ceiling
   cpu_baseline  the CPU oracle (reference op sequence on torch-CPU/LAPACK) timed on a bounded sample
+  untuned       the same K steps on the first output allocation as it comes, timed before the one-time
+                CompressPlan.tune_placement (which HBM region each stream lives in decides 2.72 vs 3.1 ms for pass 2:
+                DESIGN.md section 5); `value` is measured after it (--placement-candidates 1 turns it off)
 """
 import argparse
 import json
