@@ -346,8 +346,14 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     for (int i = 0; i < NACC * QC; ++i) accq[i] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     double q64[Q64 ? NSET : 1];   // Q64: this lane's Gram entries (one per instruction of a step), over the whole unit
+#ifndef SVDQ_Q64_CHAINS
+#define SVDQ_Q64_CHAINS 2   // independent accumulation chains per entry (even / odd k-steps), added at the end of the unit
+#endif
+    double q64b[(Q64 && SVDQ_Q64_CHAINS == 2) ? NSET : 1];
 #pragma unroll
     for (int i = 0; i < (Q64 ? NSET : 1); ++i) q64[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < ((Q64 && SVDQ_Q64_CHAINS == 2) ? NSET : 1); ++i) q64b[i] = 0.0;
     // tile (ti <= tj) number q in row-major order of the upper triangle
     auto tile_of = [](int q, int &ti, int &tj) {
         ti = 0;
@@ -427,7 +433,10 @@ UNROLL_N(4)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const double ad = (double)a[e];
-                        q64[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, ad, q64[0], 0, 0, 0);
+                        if (SVDQ_Q64_CHAINS == 2 && (e & 1))
+                            q64b[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, ad, q64b[0], 0, 0, 0);
+                        else
+                            q64[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, ad, q64[0], 0, 0, 0);
                     }
                 }
             } else {
@@ -452,8 +461,12 @@ UNROLL_N(SVDQ_UNROLL_GRAM)
                         const f32x4 a = *reinterpret_cast<const f32x4 *>(pa[st] + 16 * j);
                         const f32x4 b = *reinterpret_cast<const f32x4 *>(pb[st] + 16 * j);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            q64[st] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a[e], (double)b[e], q64[st], 0, 0, 0);
+                        for (int e = 0; e < 4; ++e) {
+                            if (SVDQ_Q64_CHAINS == 2 && (e & 1))
+                                q64b[st] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a[e], (double)b[e], q64b[st], 0, 0, 0);
+                            else
+                                q64[st] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a[e], (double)b[e], q64[st], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -561,6 +574,10 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
 
     // One fp64 partial per slot, dense [NT][NT].  Lane (c,g) holds D[4g+e][c] (fp32 MFMA) or D[g+4e][c] (fp64 MFMA).
     const int NN = NT * NT;
+    if constexpr (Q64 && SVDQ_Q64_CHAINS == 2) {
+#pragma unroll
+        for (int st = 0; st < NSET; ++st) q64[st] += q64b[st];
+    }
     if constexpr (Q64) {   // everything in the unit's first slot; N <= 8 has a second slot per unit: zeros
         const int i = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
         double *dst = gram_part + (size_t)uidx * PACK * NN;
