@@ -117,13 +117,15 @@ def profiled_traffic(kernel: str, model: str, n_tasks: int):
     """HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
     this same command on this round's binary, FETCH_SIZE doubled as the gfx950 guide prescribes).  Counters cannot be
     read from inside the run, so this is a PROFILED figure, labelled with its source; None for other workloads."""
-    if (model, n_tasks) != ("ViT-L-14", 8):
+    files = {("ViT-L-14", 8): TRAFFIC_FILE, ("ViT-L-14", 20): TRAFFIC_FILE.replace("r02_", "r02_n20_")}
+    if (model, n_tasks) not in files:
         return None, None
+    tf = files[(model, n_tasks)]
     try:
-        d = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+        d = json.load(open(os.path.join(ROOT, tf)))
         for name, v in d["kernels"].items():
             if name.startswith(kernel):
-                return int(v["hbm_bytes"]), f"{TRAFFIC_FILE} ({d.get('measured', 'n/a')})"
+                return int(v["hbm_bytes"]), f"{tf} ({d.get('measured', 'n/a')})"
     except Exception:
         pass
     return None, None
