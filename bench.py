@@ -442,20 +442,29 @@ def main():
     wl = Workload(args, rows, dev, 1234 + rank, world, on_cpu)
     # after the inputs exist: the probe walks through device memory and leaves holes in several regions behind, which
     # later allocations would be scattered over
-    ceilings = measured_ceilings(dev, walk=args.placement_candidates > 1) if rank == 0 else None
+    try:
+        ceilings = measured_ceilings(dev, walk=args.placement_candidates > 1) if rank == 0 else None
+    except Exception:
+        torch.cuda.empty_cache()
+        ceilings = None
     untuned = None
     if args.placement_candidates > 1 and not on_cpu:      # (gloo rehearsal: several ranks share one card's memory)
         e0, sc0, kms0 = wl.timed(dist, args.steps, args.warmup)
         untuned = {"ms_per_step": round(e0 / args.steps * 1e3, 4), "value": round(sc0 / (e0 / args.steps) / 1e6, 1),
                    "k_basis_project_ms": round(kms0[2], 4) if kms0[2] == kms0[2] else None,
                    "what": "the same K steps before tune_placement: outputs in the first allocation as it comes"}
-        wl.tune()
+        try:
+            wl.tune()
+        except Exception as e:      # never lose the measurement over the one-time tuning: fall back to the untuned outputs
+            torch.cuda.empty_cache()
+            wl.placement_error = f"{type(e).__name__}: {str(e)[:160]}"
     elapsed, total_scalars, kms = wl.timed(dist, args.steps, args.warmup)
     plan = wl.plan
     sm = plan.fetch_small()
     k_mean = float(sm.k.mean())
     n_units = int(plan.sizes.n_units)
     placement_ms = list(wl.placement_ms)
+    placement_error = getattr(wl, "placement_error", None)
     mask_density = round(float(sm.rows.sum()) / float(sum(rows)), 4) if args.masks != "none" else None
 
     # also the time to "small artifacts on the host" (one D2H of the packed buffer per step, which
@@ -509,7 +518,9 @@ def main():
                                             f"{len(placement_ms) // 2} candidate allocations walked through the "
                                             f"device's memory regions, pass 2 timed into each basis candidate, then "
                                             f"each mean candidate: {[round(x, 3) for x in placement_ms]} ms"
-                                            if placement_ms else "first allocation as it comes"),
+                                            if placement_ms else "first allocation as it comes" +
+                                            (f" (tune_placement failed: {placement_error})"
+                                             if placement_error else "")),
                        "masks": args.masks, "mask_density": mask_density,
                        "sharding": "none" if world == 1 else (
                            "one model per rank" if scaling == "weak" else "one model, LPT over parameter tensors")},
