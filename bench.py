@@ -478,7 +478,11 @@ def main():
             plan.fetch_small()
         d2h_ms = (time.perf_counter() - t2) / 3 * 1e3
 
-    bgather = basis_gather_ms(plan, dist, dev, on_cpu) if world > 1 else None
+    # the two extra figures must never cost the main line (every rank takes the same path: the guards are symmetric)
+    try:
+        bgather = basis_gather_ms(plan, dist, dev, on_cpu) if world > 1 else None
+    except torch.cuda.OutOfMemoryError:
+        bgather = None
 
     weak = None
     if world > 1 and scaling == "strong" and not args.no_weak:
