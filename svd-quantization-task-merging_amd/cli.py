@@ -7,7 +7,7 @@ HIP entry points of this package:
 
   Step 1  load_task_vectors           one subtraction pass for all tasks (svdq_ingest)
   Step 2  load_task_masks + combine_masks   batched mask combine (svdq_maskset_combine)
-  Step 4+5 run_basis_and_compress     the hot path: 4 launches for the whole model (svdq_compress)
+  Step 4+5 run_basis_and_compress     the hot path: six kernel launches for the whole model (svdq_compress)
   Step 6  compute_weights / cluster_tasks   N x N task Gram on the GPU (svdq_task_gram)
   Step 7  merge_all_parameters / merge_with_clustering, apply_merged_deltas (svdq_reconstruct, svdq_mask_expand)
   Step 8  compute_all_diagnostics     fused reconstruction error (svdq_recon_error)
