@@ -1,6 +1,6 @@
 """
 Fused Step 4 + Step 5 driver (reference cli.py:311-361 and cli.py:436-442): every parameter of a
-model, masked and noise regions included, goes through ONE plan -- four kernel launches and one
+model, masked and noise regions included, goes through ONE plan -- six kernel launches and one
 small D2H copy for the whole model -- and comes back as the reference's ``bases`` and
 ``compressed_all`` dictionaries.
 """

@@ -1,6 +1,6 @@
 """
 Batched driver of the HIP hot path: one plan = a ragged batch of parameter tensors x N tasks,
-four kernel launches for the whole batch, one D2H copy of the small artifacts.
+six kernel launches for the whole batch, one D2H copy of the small artifacts.
 
 This is the body of the reference's Step 4 + Step 5 (cli.py:311-361 basis loop, cli.py:436-442
 -> compress.py:173-207), re-organised so that no host round trip happens between "task deltas
