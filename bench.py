@@ -64,12 +64,16 @@ def parse():
     ap.add_argument("--no-weak", action="store_true", help="N > 1, strong: skip the additional weak-scaling leg")
     ap.add_argument("--unit-rows", type=int, default=0)
     ap.add_argument("--masks", choices=("none", "union", "intersection", "majority"), default="none",
-                    help="BASELINE configs[2]: per-task tall masks (rand > 0.7) combined on device; the four stages "
-                         "then read every task tensor through the combined mask's index list (gather mode)")
+                    help="BASELINE configs[2]: per-task tall masks (rand > 0.7) combined on device (vote + tile scan + "
+                         "unit starts, 3 launches); both passes then walk the source rows of every task tensor with the "
+                         "combined mask byte beside them and compact the selected rows in LDS (svdq_compress_masked)")
     ap.add_argument("--masks-packed", action="store_true",
                     help="hand the per-task masks over bit-packed (numpy.packbits order, the form TALL_mask files have)")
     ap.add_argument("--masks-compact", action="store_true",
                     help="A/B: materialise compacted copies of the deltas (the pre-gather schedule) instead")
+    ap.add_argument("--masks-index", action="store_true",
+                    help="A/B: int32 index lists + gather-mode passes (round 2's schedule; still what sparse masks and "
+                         "N > 16 use) instead of the mask walk (source rows + mask byte, compaction in LDS)")
     ap.add_argument("--from-base", choices=("off", "fused", "ingest"), default="off",
                     help="start from fine-tuned + base weights instead of task vectors: 'fused' forms finetuned - base "
                          "inside the streaming passes (svdq_compress_from_base), 'ingest' runs svdq_ingest first")
@@ -91,12 +95,34 @@ def parse():
 
 
 # ------------------------------------------------------------------------------------------------ launching ranks
+def visible_gpus() -> int:
+    """GPUs this process could use, without touching the HIP runtime: KFD topology nodes with SIMDs (CPU nodes report
+    simd_count 0), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES lists when set."""
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            try:
+                props = dict(line.split()[:2] for line in open(os.path.join(root, node, "properties")) if line.strip())
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(n: int) -> int:
     """Parent of `python bench.py --gpus N` without a launcher: start N fresh rank processes through
-    torch.distributed.run and hand their output through.  This process has not touched the GPU and never will
-    (torch.cuda.device_count() does not initialise it), so there is no exec / fork of a GPU-initialised process."""
+    torch.distributed.run and hand their output through.  This process never loads the HIP runtime: the GPUs are
+    counted from the KFD topology in sysfs (visible_gpus), so there is no exec / fork of a GPU-initialised process."""
     backend = os.environ.get("SVDQ_DIST_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
+    ndev = visible_gpus()
     if backend == "nccl" and n > ndev:
         print(f"bench.py: --gpus {n} needs {n} GPUs for one rank per GPU over RCCL, {ndev} visible "
               f"(set SVDQ_DIST_BACKEND=gloo to rehearse several ranks on one card)", file=sys.stderr)
@@ -277,9 +303,18 @@ class Workload:
         from svdq_amd.mask_loader import MaskSet
         args, rows, dev, plan, N = self.args, self.rows, self.dev, self.plan, self.args.tasks
         gm = torch.Generator(device=dev).manual_seed(77)
-        per_task = [[torch.rand(r, device=dev, generator=gm) > 0.7 for _ in range(N)] for r in rows]
+        # one draw per task over the concatenated parameters (a handful of launches, not one per tensor and task)
+        offs, tot = [], 0
+        for r in rows:
+            offs.append(tot)
+            tot += (r + 63) // 64 * 64      # every parameter's mask starts 64-byte aligned, as its own allocation would
+        flat = [torch.rand(tot, device=dev, generator=gm) > 0.7 for _ in range(N)]
+        per_task = [[flat[t][o:o + r] for t in range(N)] for o, r in zip(offs, rows)]
+        self._keep_masks = flat
         self.mset = mset = MaskSet(rows, dev)
         comb, counts = mset.prepare_combine(per_task, args.masks)
+        self.walk = not (args.masks_index or args.masks_compact) and N <= 16
+        self.mtab = self.ustart = None
         if args.masks_packed:
             # one bit stream per task over the concatenated parameters (first element = most significant bit)
             wts = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8, device=dev)
@@ -294,9 +329,16 @@ class Workload:
             for r in rows:
                 offs.append(acc)
                 acc += r
-            comb, it, _, ct, _ = mset.prepare_combine_packed_indices(streams, offs, args.masks, want_false=False)
-            self.itab = torch.tensor([x.data_ptr() for x in it], dtype=torch.int64).to(dev)
-            self._keep_idx = it
+            if self.walk:
+                comb, ct, self.ustart = mset.prepare_combine_packed_starts(streams, offs, args.masks, plan)
+                self.mtab = torch.tensor([c.data_ptr() for c in comb], dtype=torch.int64).to(dev)
+            else:
+                comb, it, _, ct, _ = mset.prepare_combine_packed_indices(streams, offs, args.masks, want_false=False)
+                self.itab = torch.tensor([x.data_ptr() for x in it], dtype=torch.int64).to(dev)
+                self._keep_idx = it
+        elif self.walk:
+            comb, ct, self.ustart = mset.prepare_combine_starts(per_task, args.masks, plan)
+            self.mtab = torch.tensor([c.data_ptr() for c in comb], dtype=torch.int64).to(dev)
         elif args.masks_compact:
             dt, _, ct, _ = mset.prepare_compact([c.view(torch.bool) for c in comb], self.views, want_false=False)
             self.table = plan.pointer_table(dt)
@@ -304,6 +346,7 @@ class Workload:
             it, _, ct, _ = mset.prepare_indices([c.view(torch.bool) for c in comb], want_false=False)
             self.itab = torch.tensor([x.data_ptr() for x in it], dtype=torch.int64).to(dev)
             self._keep_idx = it
+        self._keep_comb = comb
         self.rows_dev = ct
 
     @property
@@ -313,16 +356,29 @@ class Workload:
     def step(self, events=None):
         plan, args = self.plan, self.args
         if self.mset is not None:
+            fused = self.fb is not None and args.from_base == "fused"
             if args.masks_compact:
                 self.mset.run_combine()
                 self.mset.run_compact()
                 plan.run(self.table, self.rows_dev)
-            elif args.masks_packed:
-                self.mset.run_combine_packed_indices()
-                plan.run_gather(self.table, self.itab, self.rows_dev)
+            elif self.walk:
+                if args.masks_packed:
+                    self.mset.run_combine_packed_starts()
+                else:
+                    self.mset.run_combine_starts()
+                if fused:
+                    plan.run_masked_from_base(self.fb["ft_table"], self.fb["bt"], self.mtab, self.ustart, self.rows_dev)
+                else:
+                    plan.run_masked(self.table, self.mtab, self.ustart, self.rows_dev)
             else:
-                self.mset.run_combine_indices()
-                plan.run_gather(self.table, self.itab, self.rows_dev)
+                if args.masks_packed:
+                    self.mset.run_combine_packed_indices()
+                else:
+                    self.mset.run_combine_indices()
+                if fused:
+                    plan.run_gather_from_base(self.fb["ft_table"], self.fb["bt"], self.itab, self.rows_dev)
+                else:
+                    plan.run_gather(self.table, self.itab, self.rows_dev)
         elif self.fb is not None:
             if args.from_base == "fused":
                 plan.run_from_base(self.fb["ft_table"], self.fb["bt"])
@@ -410,7 +466,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         args.gpus = world
-    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    scaling = args.scaling or ("strong" if world > 1 else "none")      # one rank: nothing is scaled
     dist = None
     backend = os.environ.get("SVDQ_DIST_BACKEND", "nccl")
     if world > 1:
@@ -440,6 +496,12 @@ def main():
     rows = [rows_all[i] for i in mine]
 
     wl = Workload(args, rows, dev, 1234 + rank, world, on_cpu)
+    if os.environ.get("SVDQ_DEBUG_MAPS"):      # attribution of profiler-side crashes: library load addresses, once,
+        try:                                    # after the runtime and every library of the run are mapped
+            with open(os.environ["SVDQ_DEBUG_MAPS"], "w") as f:
+                f.write(open("/proc/self/maps").read())
+        except OSError:
+            pass
     # after the inputs exist: the probe walks through device memory and leaves holes in several regions behind, which
     # later allocations would be scattered over
     try:

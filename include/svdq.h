@@ -193,6 +193,25 @@ int svdq_compress_gather_from_base(const svdq_plan *plan, const void *finetuned_
                                    const void *index_ptrs_dev, const int64_t *rows_dev, void *workspace, void *small,
                                    void *basis, float *mean, void *stream);
 
+/* svdq_compress for MASKED parameters without index lists and without compacted copies (the default for dense masks;
+ * the same reference calls as svdq_compress_gather: apply_mask_to_tensor / get_unmasked_portion mask_loader.py:651-709
+ * inside the loops of cli.py:324-341 and compress.py:140-155).  delta_ptrs name the original full-size tensors,
+ * mask_ptrs [n_params] the combined mask of each parameter as bool bytes (combine_masks mask_loader.py:488-648),
+ * unit_start [n_units] the source position of every work unit's first row (svdq_maskset_unit_starts or
+ * svdq_maskset_combine_starts; bit 62 set = the unit takes the CLEARED elements, i.e. the noise region), rows_dev[p] the
+ * number of selected rows.  Both passes walk the source rows with contiguous loads, read the mask byte beside them and
+ * compact the selected rows into the LDS strip: 4 N + 1 bytes per source row and pass against (4 N + 4) per selected row
+ * through index lists.  Artifacts are those of svdq_compress on the compacted tensors, bit for bit.  N <= 16 tasks
+ * (SVDQ_EUNSUPPORTED above: use svdq_compress_gather). */
+int svdq_compress_masked(const svdq_plan *plan, const void *delta_ptrs, const void *mask_ptrs,
+                         const int64_t *unit_start, const int64_t *rows_dev, void *workspace_dev, void *small_dev,
+                         void *basis_dev, float *mean_dev, void *stream);
+/*      svdq_compress_masked_from_base: the same straight from checkpoints (finetuned[row] - base[row] formed in
+ *      registers, compute_task_vector task_vector_loader.py:103-141).  Bit-identical to svdq_ingest + svdq_compress_masked. */
+int svdq_compress_masked_from_base(const svdq_plan *plan, const void *finetuned_ptrs_dev, const void *base_ptrs_dev,
+                                   const void *mask_ptrs_dev, const int64_t *unit_start, const int64_t *rows_dev,
+                                   void *workspace, void *small, void *basis, float *mean, void *stream);
+
 /* ---- the step before the path: task-vector ingest and whole-tensor quantization ("TVQ"),
  * batched over a plan's parameters x tasks.  All pointer tables are DEVICE arrays of device addresses,
  * parameter-major ([p * n_tasks + t]); fp32 buffers 16-byte aligned, code buffers 4-byte aligned. ---- */
@@ -318,6 +337,33 @@ int     svdq_maskset_combine_packed_indices(const svdq_maskset *ms, const void *
                                             const void *idx_true_ptrs_dev, const void *idx_false_ptrs_dev,
                                             int64_t *count_true_dev, int64_t *count_false_dev, void *work_dev,
                                             void *stream);
+
+/* Unit starts for svdq_compress_masked instead of index lists (same reference calls: mask.sum() and flat[mask] of
+ * cli.py:332-333 / compress.py:143-144, mask_loader.py:651-709).
+ *   svdq_maskset_count_scan: per-tile counts + per-parameter exclusive scan of already combined masks (2 launches);
+ *     counts as in svdq_maskset_compact; the tile offsets stay in work_dev for svdq_maskset_unit_starts.
+ *   svdq_maskset_unit_starts: unit_start_dev[u] (int64 [plan n_units]) = source position of the element of rank
+ *     unit.row0 among the selected elements of the unit's mask, numel when the unit lies past rows_dev[p].
+ *     entry_map_dev: NULL (plan parameter p uses mask p; the plan's rows must equal the set's numel) or int32
+ *     [plan n_params]: low 31 bits = index of the mask in the set, bit 31 = take the CLEARED elements (the noise
+ *     region of cli.py:336-338).  rows_dev [plan n_params] as handed to svdq_compress_masked.
+ *   svdq_maskset_combine_starts / _combine_packed_starts: combine (bool-byte / bit-packed per-task masks, as
+ *     svdq_maskset_combine_indices / _combine_packed_indices) + scan + unit starts in 3 launches, identity map,
+ *     rows = count_true. */
+int     svdq_maskset_count_scan(const svdq_maskset *ms, const void *mask_ptrs_dev, int64_t *count_true_dev,
+                                int64_t *count_false_dev, void *work_dev, void *stream);
+int     svdq_maskset_unit_starts(const svdq_maskset *ms, const svdq_plan *plan, const void *mask_ptrs_dev,
+                                 const int32_t *entry_map_dev, const int64_t *rows_dev, const void *work_dev,
+                                 int64_t *unit_start_dev, void *stream);
+int     svdq_maskset_combine_starts(const svdq_maskset *ms, const svdq_plan *plan, const void *mask_ptrs_dev,
+                                    int32_t n_masks, int32_t strategy, const void *out_ptrs_dev,
+                                    int64_t *count_true_dev, int64_t *count_false_dev, void *work_dev,
+                                    int64_t *unit_start_dev, void *stream);
+int     svdq_maskset_combine_packed_starts(const svdq_maskset *ms, const svdq_plan *plan, const void *stream_ptrs_dev,
+                                           const int64_t *stream_bytes_dev, const int64_t *bit_offsets_dev,
+                                           int32_t n_masks, int32_t strategy, const void *out_ptrs_dev,
+                                           int64_t *count_true_dev, int64_t *count_false_dev, void *work_dev,
+                                           int64_t *unit_start_dev, void *stream);
 
 /* ---- merge consumers (the parity reconstruction of R14)
  *      svdq_reconstruct: reconstruct_from_coefficients (merge.py:144-194):

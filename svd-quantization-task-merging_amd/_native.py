@@ -86,6 +86,17 @@ SIGNATURES = {
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_maskset_combine_packed_indices": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
                                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_maskset_count_scan": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_maskset_unit_starts": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
+    "svdq_maskset_combine_starts": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_maskset_combine_packed_starts": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_compress_masked": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
+    "svdq_compress_masked_from_base": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "svdq_compress_gather": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
     "svdq_compress_from_base": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -247,7 +247,8 @@ static void unit_range(const svdq_plan *pl, int32_t param0, int32_t nparams, int
 }
 
 static int gram_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, int32_t param0,
-                      int32_t nparams, const void *idx, void *stream, const void *base = nullptr) {
+                      int32_t nparams, const void *idx, void *stream, const void *base = nullptr,
+                      const int64_t *ustart = nullptr) {
     if (!pl || !ptrs || !workspace) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
@@ -259,7 +260,7 @@ static int gram_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows
     // for the parameters the eigen-stage flags (eig_range).  cfg.reserved bit 1 keeps fp32 products throughout (A/B).
     const int f64 = (pl->ntp <= 16 && !(pl->cfg.reserved & 2)) ? 1 : 0;
     return svdq_launch_gram(pl, ptrs, rows_dev, reinterpret_cast<double *>(ws(workspace, pl->ws_gram_off)), u0, nu,
-                            pl->cfg.center, idx, base, f64, nullptr, (hipStream_t)stream);
+                            pl->cfg.center, idx, base, f64, nullptr, (hipStream_t)stream, ustart);
 }
 
 extern "C" int svdq_gram_center_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace,
@@ -284,7 +285,8 @@ extern "C" int svdq_task_gram(const svdq_plan *pl, const void *ptrs, const int64
 }
 
 static int eig_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, void *small,
-                     int32_t param0, int32_t nparams, const void *idx, void *stream, const void *base = nullptr) {
+                     int32_t param0, int32_t nparams, const void *idx, void *stream, const void *base = nullptr,
+                     const int64_t *ustart = nullptr) {
     if (!pl || !ptrs || !workspace || !small) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
@@ -299,7 +301,8 @@ static int eig_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
     const bool refine = pl->ntp > 16 && !(pl->cfg.reserved & 2);
     int32_t *flags = refine ? reinterpret_cast<int32_t *>(ws(workspace, pl->ws_flag_off)) : nullptr;
     if (int rc = svdq_launch_reduce(pl, part, part2, param0, nparams, nullptr, st)) return rc;
-    if (int rc = svdq_launch_eig(pl, ptrs, rows_dev, part2, W, c0, sm, param0, nparams, idx, base, nullptr, flags, st))
+    if (int rc = svdq_launch_eig(pl, ptrs, rows_dev, part2, W, c0, sm, param0, nparams, idx, base, nullptr, flags, st,
+                                 ustart))
         return rc;
     if (!refine) return SVDQ_OK;
     // N > 16: the parameters whose spectrum reaches into the band fp32-product sums do not resolve are accumulated
@@ -307,9 +310,10 @@ static int eig_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
     // once, so a batch without such a parameter pays three near-empty launches
     int u0, nu;
     unit_range(pl, param0, nparams, &u0, &nu);
-    if (int rc = svdq_launch_gram(pl, ptrs, rows_dev, part, u0, nu, pl->cfg.center, idx, base, 1, flags, st)) return rc;
+    if (int rc = svdq_launch_gram(pl, ptrs, rows_dev, part, u0, nu, pl->cfg.center, idx, base, 1, flags, st, ustart))
+        return rc;
     if (int rc = svdq_launch_reduce(pl, part, part2, param0, nparams, flags, st)) return rc;
-    return svdq_launch_eig(pl, ptrs, rows_dev, part2, W, c0, sm, param0, nparams, idx, base, flags, nullptr, st);
+    return svdq_launch_eig(pl, ptrs, rows_dev, part2, W, c0, sm, param0, nparams, idx, base, flags, nullptr, st, ustart);
 }
 
 extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
@@ -320,7 +324,7 @@ extern "C" int svdq_eig_rank_select_range(const svdq_plan *pl, const void *ptrs,
 
 static int bp_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, void *workspace, const void *small,
                     void *basis, float *mean, int32_t param0, int32_t nparams, const void *idx, void *stream,
-                    const void *base = nullptr) {
+                    const void *base = nullptr, const int64_t *ustart = nullptr) {
     if (!pl || !ptrs || !workspace || !small || !basis) {
         svdq_set_error("null argument");
         return SVDQ_EINVAL;
@@ -338,7 +342,7 @@ static int bp_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_d
                                      reinterpret_cast<const int32_t *>(sm + pl->small.r_off),
                                      reinterpret_cast<uint8_t *>(basis), mean,
                                      reinterpret_cast<double *>(ws(workspace, pl->ws_cpart_off)), u0, nu,
-                                     pl->cfg.reserved & 5, idx, base, (hipStream_t)stream);
+                                     pl->cfg.reserved & 5, idx, base, (hipStream_t)stream, ustart);
 }
 
 extern "C" int svdq_basis_project_range(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev,
@@ -463,6 +467,66 @@ extern "C" int svdq_compress_gather_from_base(const svdq_plan *pl, const void *f
     if (rc == SVDQ_OK)
         rc = bp_range(pl, finetuned_ptrs, rows_dev, workspace, small, basis, mean, 0, pl->n_params, index_ptrs, stream,
                       base_ptrs);
+    if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
+    return rc;
+}
+
+// Masked parameters WITHOUT index lists (the default for dense masks; reference cli.py:324-341 +
+// mask_loader.py:651-709 applied inside the two passes): delta_ptrs name the ORIGINAL (full-size) tensors, mask_ptrs[p]
+// the combined mask of parameter p as bool bytes, unit_start the source position of every work unit's first row
+// (svdq_maskset_unit_starts / _combine_starts; its bit 62 selects the cleared elements -- the noise region) and
+// rows_dev[p] how many rows parameter p has.  The passes walk the source rows, read the mask beside them and compact
+// the selected rows into the LDS strip on the fly: 4 N + 1 bytes per source row and pass, no index lists, no compacted
+// copies.  Outputs are those of svdq_compress on the compacted tensors, bit for bit.  N <= 16.
+extern "C" int svdq_compress_masked(const svdq_plan *pl, const void *ptrs, const void *mask_ptrs,
+                                    const int64_t *unit_start, const int64_t *rows_dev, void *workspace, void *small,
+                                    void *basis, float *mean, void *stream) {
+    if (!pl || !mask_ptrs || !unit_start || !rows_dev) {
+        svdq_set_error("svdq_compress_masked: plan, mask_ptrs, unit_start and rows_dev are required");
+        return SVDQ_EINVAL;
+    }
+    if (pl->ntp > 16) {
+        svdq_set_error("the mask-walk mode covers N <= 16 tasks (got %d): use the index lists (svdq_compress_gather)",
+                       pl->n_tasks);
+        return SVDQ_EUNSUPPORTED;
+    }
+    if (small)
+        HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(small) + pl->small.status_off, 0, sizeof(int32_t),
+                               (hipStream_t)stream));
+    int rc = gram_range(pl, ptrs, rows_dev, workspace, 0, pl->n_params, mask_ptrs, stream, nullptr, unit_start);
+    if (rc == SVDQ_OK)
+        rc = eig_range(pl, ptrs, rows_dev, workspace, small, 0, pl->n_params, mask_ptrs, stream, nullptr, unit_start);
+    if (rc == SVDQ_OK)
+        rc = bp_range(pl, ptrs, rows_dev, workspace, small, basis, mean, 0, pl->n_params, mask_ptrs, stream, nullptr,
+                      unit_start);
+    if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
+    return rc;
+}
+
+// The same straight from checkpoints: finetuned[row] - base[row] is formed in registers in both passes.
+// Bit-identical to svdq_ingest followed by svdq_compress_masked.
+extern "C" int svdq_compress_masked_from_base(const svdq_plan *pl, const void *finetuned_ptrs, const void *base_ptrs,
+                                              const void *mask_ptrs, const int64_t *unit_start, const int64_t *rows_dev,
+                                              void *workspace, void *small, void *basis, float *mean, void *stream) {
+    if (!pl || !base_ptrs || !mask_ptrs || !unit_start || !rows_dev) {
+        svdq_set_error("svdq_compress_masked_from_base: plan, base_ptrs, mask_ptrs, unit_start and rows_dev are required");
+        return SVDQ_EINVAL;
+    }
+    if (pl->ntp > 16) {
+        svdq_set_error("the mask-walk mode covers N <= 16 tasks (got %d): use the index lists "
+                       "(svdq_compress_gather_from_base)", pl->n_tasks);
+        return SVDQ_EUNSUPPORTED;
+    }
+    if (small)
+        HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(small) + pl->small.status_off, 0, sizeof(int32_t),
+                               (hipStream_t)stream));
+    int rc = gram_range(pl, finetuned_ptrs, rows_dev, workspace, 0, pl->n_params, mask_ptrs, stream, base_ptrs, unit_start);
+    if (rc == SVDQ_OK)
+        rc = eig_range(pl, finetuned_ptrs, rows_dev, workspace, small, 0, pl->n_params, mask_ptrs, stream, base_ptrs,
+                       unit_start);
+    if (rc == SVDQ_OK)
+        rc = bp_range(pl, finetuned_ptrs, rows_dev, workspace, small, basis, mean, 0, pl->n_params, mask_ptrs, stream,
+                      base_ptrs, unit_start);
     if (rc == SVDQ_OK) rc = svdq_coeff_quantize(pl, workspace, small, stream);
     return rc;
 }

@@ -63,19 +63,21 @@ void svdq_set_error(const char *fmt, ...);
 // idx: NULL, or a device table [n_params] of int32 index lists (gather mode, see svdq_compress_gather);
 // base: NULL, or a device table [n_params] of base tensors (minus-base mode, see svdq_compress_from_base);
 // only: NULL, or a device table [n_params] of int32 -- parameters whose entry is 0 are skipped (refinement pass)
+// ustart: NULL, or the walk mode's per-unit source start positions [n_units] (svdq_maskset_*_starts); idx then names
+// the combined MASK byte tensors instead of index lists (svdq_compress_masked)
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
                      int unit0, int nunits, int center, const void *idx, const void *base, int f64,
-                     const int32_t *only, hipStream_t st);
+                     const int32_t *only, hipStream_t st, const int64_t *ustart = nullptr);
 int svdq_launch_gram_total(const svdq_plan *pl, const double *part2, double *out, hipStream_t st);
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
                               double *cpart, int unit0, int nunits, int reverse, const void *idx, const void *base,
-                              hipStream_t st);
+                              hipStream_t st, const int64_t *ustart = nullptr);
 // refine_out: NULL, or a device table [n_params] that receives 1 where a singular value lies in the band the fp32-product
 // Gram does not resolve (then the caller re-accumulates those parameters in fp64 and calls again with only = that table)
 int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W,
                     double *c0, uint8_t *small, int param0, int nparams, const void *idx, const void *base,
-                    const int32_t *only, int32_t *refine_out, hipStream_t st);
+                    const int32_t *only, int32_t *refine_out, hipStream_t st, const int64_t *ustart = nullptr);
 int svdq_launch_reduce(const svdq_plan *pl, const double *part, double *part2, int param0, int nparams,
                        const int32_t *only, hipStream_t st);
 int svdq_launch_coeff(const svdq_plan *pl, const double *cpart, const double *c0, uint8_t *small, int param0,

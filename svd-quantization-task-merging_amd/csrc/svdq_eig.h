@@ -6,6 +6,11 @@
 
 #define LDN 33  // padded leading dimension of N x N LDS matrices sized for N <= 32 (k_coeff)
 
+// phase stamps for tools/probe/eig_time.hip (a diagnostic build defines EIG_STAMP; nothing is emitted otherwise)
+#ifndef EIG_STAMP
+#define EIG_STAMP(i)
+#endif
+
 // Rotation (c, s) that annihilates a_pq.  The ANGLE only has to be good enough to make the sweep
 // converge (it is seeded in fp32: one v_rcp/v_sqrt instead of two fp64 divides and two fp64 square
 // roots on the critical path of every round); ORTHOGONALITY must hold to fp64, so c = (1+t^2)^-1/2 is
@@ -79,7 +84,7 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
                           const double *__restrict__ gram_part2, float *__restrict__ Wtab,
                           double *__restrict__ c0_out, float *__restrict__ sigma_out, int32_t *__restrict__ k_out,
                           int32_t *__restrict__ r_out, float *__restrict__ energy_out,
-                          int64_t *__restrict__ rows_out, const int32_t *const *__restrict__ idx_ptrs = nullptr,
+                          int64_t *__restrict__ rows_out, int64_t row0_pos = 0,
                           const float *const *__restrict__ base_ptrs = nullptr,
                           int32_t *__restrict__ refine_out = nullptr, double resolve = 1e-6) {
 #pragma clang fp contract(off)
@@ -93,6 +98,7 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
     int &s_i0 = order[NMAX];
 
     const int n = NT, nn = NT * NT;
+    EIG_STAMP(0);
 
     // fixed-order sum of the SVDQ_RC level-2 partials
     for (int e = tid; e < nn; e += THREADS) {
@@ -103,6 +109,7 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
         Gd[e] = a;
     }
     phase_sync<THREADS>();
+    EIG_STAMP(1);
 
     // Centred rows sum to zero, so 1/sqrt(N) is an exact null vector of Tc.  Deflate that direction explicitly in fp64
     // (the fp32 rounding of the centred rows leaves ~1e-7 sigma_0 of it in the data):
@@ -135,6 +142,7 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
     }
     phase_sync<THREADS>();
 
+    EIG_STAMP(2);
     // Parallel-order cyclic Jacobi: a round-robin tournament pairs all indices into M = ceil(n/2)
     // disjoint (p,q) per round (ne - 1 rounds per sweep); the M rotations of a round commute, so they
     // are applied together: A <- A J (columns), then A <- J^T A (rows), V <- V J.
@@ -218,6 +226,7 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
         }
     }
     phase_sync<THREADS>();
+    EIG_STAMP(3);
 
     // sort descending (stable on ties), sign convention: largest-|v| component positive
     if (tid < n) lam[tid] = A[tid * LDX + tid];
@@ -246,6 +255,7 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
     phase_sync<THREADS>();
 
     const int r = (int)(D < (int64_t)n ? D : (int64_t)n);
+    EIG_STAMP(4);
     if (tid == 0) {
         // basis.py:147-156 and :199-211, fp32 like the reference (threshold compared as fp32)
         float S[NMAX], cum[NMAX];
@@ -292,6 +302,7 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
             refine_out[p] = need;
         }
     }
+    EIG_STAMP(5);
     // W[t][i] = sgn_i V[t][order[i]] / sigma_i for the resolved directions, 0 otherwise (A is free now)
     const double s0 = sig[0];
     for (int e = tid; e < nn; e += THREADS) {
@@ -300,14 +311,15 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
         if (i < r && sig[i] > resolve * s0 && sig[i] > 0.0) wv = sgn[i] * V[t * LDX + order[i]] / sig[i];
         A[t * LDX + i] = wv;
     }
-    // row 0 of every task (gather mode: the first selected element of the tensor)
+    // row 0 of every task (gather / walk mode: the first selected element of the tensor, row0_pos)
     if (tid < n && D > 0) {
-        const int64_t i0 = idx_ptrs ? idx_ptrs[p][0] : 0;
+        const int64_t i0 = row0_pos;
         float x0 = ptrs[(size_t)p * n + tid][i0];
         if (base_ptrs) x0 = x0 - base_ptrs[p][i0];   // minus-base mode: the delta is formed exactly as in the passes
         lam[tid] = (double)x0;
     }
     phase_sync<THREADS>();
+    EIG_STAMP(6);
 
     // Orthonormal completion of the first null direction (the one centring always creates; LAPACK
     // returns an arbitrary orthonormal vector there): u = (e_0 - U U[0,:]^T) / norm, i.e. one more W
@@ -340,6 +352,7 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
         }
     }
     phase_sync<THREADS>();
+    EIG_STAMP(7);
     const bool have_col = spike != 0.0;
     if (tid == 0) {
         float *aux = Wtab + (size_t)p * (nn + 4) + nn;
@@ -367,5 +380,6 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
         }
         c0_out[(size_t)p * nn + e] = cv;
     }
+    EIG_STAMP(8);
 }
 

@@ -1301,6 +1301,216 @@ extern "C" int svdq_maskset_combine_packed_indices(const svdq_maskset *ms, const
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
+// ------------------------------------------------------------------------------------ walk mode: unit starts
+// The mask-walk mode of the streaming passes (svdq_compress_masked, svdq_stream.hip "walk mode") needs, for every work
+// unit of the plan, the SOURCE position of the unit's first row -- the element of rank unit.row0 among the selected
+// (or, for the noise region, the cleared) elements of its mask.  One wavefront per unit: a 64-ary search over the
+// exclusive tile offsets of the scan, then one pass over the 2048 mask bytes of the tile that holds the element.
+// entry_map: NULL (plan parameter p uses mask p, selected elements) or [n_params] int32: low 31 bits = which mask of the
+// set, bit 31 = the cleared elements.  Units past rows_dev[p] get numel (nothing to walk).  Bit 62 of every start
+// carries the polarity to the streaming kernels.
+#define SVDQ_WALK_INV (1ll << 62)
+__global__ __launch_bounds__(64) void k_maskset_unit_starts(const SvdqParam *__restrict__ params,
+                                                            const SvdqUnit *__restrict__ units,
+                                                            const int64_t *__restrict__ rows_dev,
+                                                            const int32_t *__restrict__ entry_map,
+                                                            const int32_t *__restrict__ tile_begin,
+                                                            const int64_t *__restrict__ numel_tab,
+                                                            const uint8_t *const *__restrict__ masks,
+                                                            const unsigned long long *__restrict__ tile_offsets,
+                                                            int64_t *__restrict__ ustart) {
+    const int u = blockIdx.x, lane = threadIdx.x;
+    const SvdqUnit ud = units[u];
+    const int p = ud.param;
+    const unsigned em = entry_map ? (unsigned)entry_map[p] : (unsigned)p;
+    const int q = (int)(em & 0x7fffffffu), inv = (int)(em >> 31);
+    const int64_t numel = numel_tab[q];
+    const int64_t tag = inv ? SVDQ_WALK_INV : 0;
+    const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
+    if (ud.row0 >= D) {
+        if (lane == 0) ustart[u] = numel | tag;
+        return;
+    }
+    const unsigned long long target = (unsigned long long)ud.row0;
+    const int t0 = tile_begin[q], nt = tile_begin[q + 1] - t0;
+    // off(i) = selected elements in front of tile i
+    auto off = [&](int i) -> unsigned long long {
+        const unsigned long long t = tile_offsets[t0 + i];
+        return inv ? (unsigned long long)i * MASK_TILE - t : t;
+    };
+    int lo = 0, hi = nt;   // invariant: off(lo) <= target, the answer is the largest such tile in [lo, hi)
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) / 64;
+        const int i = lo + lane * step;
+        const bool ok = i < hi && off(i) <= target;
+        const int j = (int)__popcll(__ballot(ok)) - 1;   // off is monotone: lanes 0..j pass, lane 0 always does
+        const int nlo = lo + (j < 0 ? 0 : j) * step;
+        hi = (nlo + step < hi) ? nlo + step : hi;
+        lo = nlo;
+    }
+    const unsigned rem = (unsigned)(target - off(lo));   // rank inside the tile
+    const int64_t tb = (int64_t)lo * MASK_TILE;
+    const uint8_t *m = masks[q] + tb + 32 * lane;
+    unsigned bits = 0;
+    const int64_t left = numel - (tb + 32 * lane);
+    if (left >= 32 && (reinterpret_cast<uintptr_t>(m) & 7) == 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned long long x = reinterpret_cast<const unsigned long long *>(m)[w];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bits |= (unsigned)(((x >> (8 * e)) & 0xff) != 0) << (8 * w + e);
+        }
+    } else {
+        for (int e = 0; e < 32; ++e)
+            if (e < left) bits |= (unsigned)(m[e] != 0) << e;
+    }
+    if (inv) {
+        bits = ~bits;
+        if (left < 32) bits &= left > 0 ? ((1u << left) - 1u) : 0u;
+    }
+    const unsigned cnt = __popc(bits);
+    unsigned incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const unsigned excl = incl - cnt;
+    const bool mine = excl <= rem && rem < incl;
+    if (mine) {
+        unsigned b = bits;
+        for (unsigned i = excl; i < rem; ++i) b &= b - 1;   // drop the set bits in front of ours
+        ustart[u] = (tb + 32 * lane + (__ffs(b) - 1)) | tag;
+    }
+    if (__ballot(mine) == 0 && lane == 0) ustart[u] = numel | tag;   // counts and mask disagree: nothing to walk
+}
+
+static int maskset_check_plan(const svdq_maskset *ms, const svdq_plan *pl, const char *who, bool identity) {
+    if (!ms || !pl) {
+        svdq_set_error("%s: bad argument", who);
+        return SVDQ_EINVAL;
+    }
+    if (identity) {
+        if (pl->n_params != ms->n_params) {
+            svdq_set_error("%s: the plan has %d parameters, the mask set %d", who, pl->n_params, ms->n_params);
+            return SVDQ_EINVAL;
+        }
+        for (int q = 0; q < ms->n_params; ++q)
+            if (pl->h_params[q].rows != ms->h_numel[q]) {
+                svdq_set_error("Shape mismatch: parameter %d has %lld elements in the plan and %lld in the mask set", q,
+                               (long long)pl->h_params[q].rows, (long long)ms->h_numel[q]);
+                return SVDQ_EINVAL;
+            }
+    }
+    return SVDQ_OK;
+}
+
+static void launch_unit_starts(const svdq_maskset *ms, const svdq_plan *pl, const uint8_t *const *mp,
+                               const int32_t *entry_map, const int64_t *rows_dev,
+                               const unsigned long long *tile_offsets, int64_t *unit_start, hipStream_t st) {
+    hipLaunchKernelGGL(k_maskset_unit_starts, dim3(pl->n_units), dim3(64), 0, st, pl->d_params, pl->d_units, rows_dev,
+                       entry_map, ms->d_tile_begin, ms->d_numel, mp, tile_offsets, unit_start);
+}
+
+extern "C" int svdq_maskset_count_scan(const svdq_maskset *ms, const void *mask_ptrs, int64_t *count_true,
+                                       int64_t *count_false, void *work, void *stream) {
+    if (!ms || !mask_ptrs || !count_true || !work) {
+        svdq_set_error("svdq_maskset_count_scan: bad argument");
+        return SVDQ_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *wb = reinterpret_cast<uint8_t *>(work);
+    unsigned *tile_counts = reinterpret_cast<unsigned *>(wb);
+    unsigned long long *tile_offsets =
+        reinterpret_cast<unsigned long long *>(wb + svdq_align_up((int64_t)ms->n_tiles * 4, 256));
+    hipLaunchKernelGGL(k_maskset_count, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param, ms->d_tile_begin,
+                       ms->d_numel, reinterpret_cast<const uint8_t *const *>(mask_ptrs), tile_counts);
+    hipLaunchKernelGGL(k_maskset_scan, dim3(ms->n_params), dim3(1024), 0, st, ms->d_tile_begin, ms->d_numel, tile_counts,
+                       tile_offsets, reinterpret_cast<long long *>(count_true),
+                       reinterpret_cast<long long *>(count_false));
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+extern "C" int svdq_maskset_unit_starts(const svdq_maskset *ms, const svdq_plan *pl, const void *mask_ptrs,
+                                        const int32_t *entry_map, const int64_t *rows_dev, const void *work,
+                                        int64_t *unit_start, void *stream) {
+    if (!mask_ptrs || !rows_dev || !work || !unit_start) {
+        svdq_set_error("svdq_maskset_unit_starts: bad argument");
+        return SVDQ_EINVAL;
+    }
+    if (int rc = maskset_check_plan(ms, pl, "svdq_maskset_unit_starts", entry_map == nullptr)) return rc;
+    const uint8_t *wb = reinterpret_cast<const uint8_t *>(work);
+    auto tile_offsets = reinterpret_cast<const unsigned long long *>(wb + svdq_align_up((int64_t)ms->n_tiles * 4, 256));
+    launch_unit_starts(ms, pl, reinterpret_cast<const uint8_t *const *>(mask_ptrs), entry_map, rows_dev, tile_offsets,
+                       unit_start, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+extern "C" int svdq_maskset_combine_starts(const svdq_maskset *ms, const svdq_plan *pl, const void *mask_ptrs,
+                                           int32_t n_masks, int32_t strategy, const void *out_ptrs, int64_t *count_true,
+                                           int64_t *count_false, void *work, int64_t *unit_start, void *stream) {
+    if (!mask_ptrs || !out_ptrs || !count_true || !work || !unit_start || n_masks < 1) {
+        svdq_set_error(n_masks < 1 ? "Empty mask list" : "svdq_maskset_combine_starts: bad argument");
+        return SVDQ_EINVAL;
+    }
+    if (strategy < 0 || strategy > 2) {
+        svdq_set_error("Unknown mask strategy: %d", strategy);
+        return SVDQ_EINVAL;
+    }
+    if (int rc = maskset_check_plan(ms, pl, "svdq_maskset_combine_starts", true)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *wb = reinterpret_cast<uint8_t *>(work);
+    unsigned *tile_counts = reinterpret_cast<unsigned *>(wb);
+    unsigned long long *tile_offsets =
+        reinterpret_cast<unsigned long long *>(wb + svdq_align_up((int64_t)ms->n_tiles * 4, 256));
+    auto op = reinterpret_cast<uint8_t *const *>(out_ptrs);
+    hipLaunchKernelGGL(k_maskset_combine, dim3(ms->n_tiles), dim3(ELT_THREADS), 0, st, ms->d_tile_param,
+                       ms->d_tile_begin, ms->d_numel, reinterpret_cast<const uint8_t *const *>(mask_ptrs), n_masks,
+                       strategy, op, (unsigned long long *)nullptr, tile_counts);
+    hipLaunchKernelGGL(k_maskset_scan, dim3(ms->n_params), dim3(1024), 0, st, ms->d_tile_begin, ms->d_numel, tile_counts,
+                       tile_offsets, reinterpret_cast<long long *>(count_true),
+                       reinterpret_cast<long long *>(count_false));
+    launch_unit_starts(ms, pl, reinterpret_cast<const uint8_t *const *>(out_ptrs), nullptr, count_true, tile_offsets,
+                       unit_start, st);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+extern "C" int svdq_maskset_combine_packed_starts(const svdq_maskset *ms, const svdq_plan *pl, const void *stream_ptrs,
+                                                  const int64_t *stream_bytes, const int64_t *bit_offsets,
+                                                  int32_t n_masks, int32_t strategy, const void *out_ptrs,
+                                                  int64_t *count_true, int64_t *count_false, void *work,
+                                                  int64_t *unit_start, void *stream) {
+    if (!stream_ptrs || !stream_bytes || !bit_offsets || !out_ptrs || !count_true || !work || !unit_start ||
+        n_masks < 1) {
+        svdq_set_error(n_masks < 1 ? "Empty mask list" : "svdq_maskset_combine_packed_starts: bad argument");
+        return SVDQ_EINVAL;
+    }
+    if (n_masks > SVDQ_MAX_TASKS) {
+        svdq_set_error("at most %d packed mask streams are supported, got %d", SVDQ_MAX_TASKS, n_masks);
+        return SVDQ_EINVAL;
+    }
+    if (strategy < 0 || strategy > 2) {
+        svdq_set_error("Unknown mask strategy: %d", strategy);
+        return SVDQ_EINVAL;
+    }
+    if (int rc = maskset_check_plan(ms, pl, "svdq_maskset_combine_packed_starts", true)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *wb = reinterpret_cast<uint8_t *>(work);
+    unsigned *tile_counts = reinterpret_cast<unsigned *>(wb);
+    unsigned long long *tile_offsets =
+        reinterpret_cast<unsigned long long *>(wb + svdq_align_up((int64_t)ms->n_tiles * 4, 256));
+    hipLaunchKernelGGL(k_maskset_combine_packed, dim3((ms->n_tiles + MASK_TPB - 1) / MASK_TPB), dim3(ELT_THREADS), 0, st,
+                       ms->d_tile_param, ms->d_tile_begin, ms->d_numel,
+                       reinterpret_cast<const uint8_t *const *>(stream_ptrs), bit_offsets, stream_bytes, n_masks,
+                       strategy, reinterpret_cast<uint8_t *const *>(out_ptrs), tile_counts, ms->n_tiles);
+    hipLaunchKernelGGL(k_maskset_scan, dim3(ms->n_params), dim3(1024), 0, st, ms->d_tile_begin, ms->d_numel, tile_counts,
+                       tile_offsets, reinterpret_cast<long long *>(count_true),
+                       reinterpret_cast<long long *>(count_false));
+    launch_unit_starts(ms, pl, reinterpret_cast<const uint8_t *const *>(out_ptrs), nullptr, count_true, tile_offsets,
+                       unit_start, st);
+    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
 // ------------------------------------------------------------------------------------ diagnostics
 // compute_reconstruction_error (diagnostics.py:72-117) fused with the reconstruction it is applied to in
 // compute_parameter_diagnostics (diagnostics.py:205-215): rec = U_high c_high + U_low c_low (+ mean when

@@ -37,12 +37,18 @@ __device__ void reduce_partials(const double *__restrict__ part, int s0, int s1,
     __syncthreads();
 }
 
-// First-level reduction, spread over the chip: chunk c of parameter p sums its share of the unit slots
-// (canonical order: chunk_sum) into part2[(p*SVDQ_RC + c)][nn]; k_eig / k_coeff then only add SVDQ_RC
-// partials per parameter.  Keeps the whole reduction deterministic and off one CU.
-__global__ __launch_bounds__(64) void k_reduce(const SvdqParam *__restrict__ params, int NT, int pack,
-                                               const double *__restrict__ part, double *__restrict__ part2,
-                                               int param0, const int32_t *__restrict__ only) {
+// First-level reduction, spread over the chip: chunk c of parameter p sums its share of the unit slots into
+// part2[(p*SVDQ_RC + c)][nn]; k_eig / k_coeff then only add SVDQ_RC partials per parameter.  Keeps the whole reduction
+// deterministic and off one CU.  Latency-bound (a chunk of a 4 M-row tensor is 128 slots of N x N doubles, each thread
+// adds its entry of every slot): 256 threads = G groups of >= nn threads; group g takes slots a + g, a + g + G, ...
+// with eight loads in flight per thread, the G group sums meet in LDS in group order.  Fixed order, so the same bits
+// in every run and every batch; 4 dependent memory round trips per chunk where the 64-thread version had 16.
+#define RED_THREADS 256
+__global__ __launch_bounds__(RED_THREADS) void k_reduce(const SvdqParam *__restrict__ params, int NT, int pack,
+                                                        const double *__restrict__ part, double *__restrict__ part2,
+                                                        int param0, const int32_t *__restrict__ only) {
+#pragma clang fp contract(off)
+    __shared__ double red[RED_THREADS];
     const int p = param0 + blockIdx.x, c = blockIdx.y, nn = NT * NT;
     if (only && !only[p]) return;
     const SvdqParam pd = params[p];
@@ -51,12 +57,42 @@ __global__ __launch_bounds__(64) void k_reduce(const SvdqParam *__restrict__ par
     if (ub > pd.unit_count) ub = pd.unit_count;
     if (ua > ub) ua = ub;
     const int a = (pd.unit_begin + ua) * pack, b = (pd.unit_begin + ub) * pack;
-    for (int e = threadIdx.x; e < nn; e += 64) part2[((size_t)p * SVDQ_RC + c) * nn + e] = chunk_sum(part, a, b, nn, e);
+    const int width = nn <= 64 ? 64 : (nn <= 128 ? 128 : RED_THREADS);   // threads per group
+    const int G = RED_THREADS / width;
+    const int g = threadIdx.x / width, l = threadIdx.x % width;
+    double *dst = part2 + ((size_t)p * SVDQ_RC + c) * nn;
+    for (int e0 = 0; e0 < nn; e0 += width) {      // one round unless nn > 256
+        const int e = e0 + l;
+        double acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+        if (e < nn) {
+            int s = a + g;
+            for (; s + 7 * G < b; s += 8 * G) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(s + u * G) * nn + e];
+            }
+            for (; s < b; s += G) acc[0] += part[(size_t)s * nn + e];
+        }
+        const double mine = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        if (G == 1) {
+            if (e < nn) dst[e] = mine;
+        } else {
+            red[threadIdx.x] = mine;
+            __syncthreads();
+            if (g == 0 && e < nn) {
+                double t = red[l];
+                for (int j = 1; j < G; ++j) t += red[j * width + l];
+                dst[e] = t;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 int svdq_launch_reduce(const svdq_plan *pl, const double *part, double *part2, int param0, int nparams,
                        const int32_t *only, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce, dim3(nparams, SVDQ_RC), dim3(64), 0, st, pl->d_params, pl->n_tasks, pl->pack,
+    hipLaunchKernelGGL(k_reduce, dim3(nparams, SVDQ_RC), dim3(RED_THREADS), 0, st, pl->d_params, pl->n_tasks, pl->pack,
                        part, part2, param0, only);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
@@ -101,13 +137,20 @@ __global__ __launch_bounds__(THREADS) void k_eig(const SvdqParam *__restrict__ p
                                                  const int32_t *const *__restrict__ idx_ptrs,
                                                  const float *const *__restrict__ base_ptrs,
                                                  const int32_t *__restrict__ only, int32_t *__restrict__ refine_out,
-                                                 float resolve) {
+                                                 float resolve, const int64_t *__restrict__ ustart) {
     __shared__ __attribute__((aligned(16))) double lds[SVDQ_EIG_LDS_BYTES(NMAX) / 8 + 1];
     const int p = param0 + blockIdx.x;
     if (only && !only[p]) return;
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
+    // source position of the parameter's first row: 0, the first entry of its index list (gather mode), or the start
+    // of its first work unit (walk mode; bit 62 is the mask polarity)
+    int64_t row0 = 0;
+    if (D > 0) {
+        if (idx_ptrs) row0 = idx_ptrs[p][0];
+        else if (ustart) row0 = ustart[params[p].unit_begin] & ((1ll << 62) - 1);
+    }
     eig_param<THREADS, NMAX>(lds, p, threadIdx.x, D, ptrs, NT, center, thr, max_rank, gram_part2, Wtab, c0_out, sigma_out,
-                             k_out, r_out, energy_out, rows_out, idx_ptrs, base_ptrs, refine_out, (double)resolve);
+                             k_out, r_out, energy_out, rows_out, row0, base_ptrs, refine_out, (double)resolve);
 }
 
 // ------------------------------------------------------------------------------------ epilogue
@@ -196,7 +239,8 @@ __global__ __launch_bounds__(EIG_THREADS) void k_coeff(const SvdqParam *__restri
 // ------------------------------------------------------------------------------------ launchers
 int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part2, float *W,
                     double *c0, uint8_t *small, int param0, int nparams, const void *idx, const void *base,
-                    const int32_t *only, int32_t *refine_out, hipStream_t st) {
+                    const int32_t *only, int32_t *refine_out, hipStream_t st, const int64_t *ustart) {
+    if (ustart) idx = nullptr;   // walk mode: idx names mask bytes, not index lists
     // smallest sigma / sigma_0 the Gram behind gram_part2 resolves: exact-product (fp64 MFMA) sums reach the fp32
     // resolution of the data; fp32-product sums (cfg.reserved bit 1, and N > 16 before its refinement) do not
     const bool exact = (pl->ntp <= 16 && !(pl->cfg.reserved & 2)) || only != nullptr;
@@ -212,11 +256,11 @@ int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_d
     if (pl->n_tasks <= 8)
         hipLaunchKernelGGL((k_eig<64, 8>), dim3(nparams), dim3(64), 0, st, pl->d_params, pp, rows_dev, pl->n_tasks,
                            pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part2, W, c0, param0, sg,
-                           kk, rr, en, ro, ip, bpp, only, refine_out, resolve);
+                           kk, rr, en, ro, ip, bpp, only, refine_out, resolve, ustart);
     else
         hipLaunchKernelGGL((k_eig<256, 32>), dim3(nparams), dim3(256), 0, st, pl->d_params, pp, rows_dev, pl->n_tasks,
                            pl->cfg.center, pl->cfg.energy_threshold, pl->cfg.max_rank, gram_part2, W, c0, param0, sg,
-                           kk, rr, en, ro, ip, bpp, only, refine_out, resolve);
+                           kk, rr, en, ro, ip, bpp, only, refine_out, resolve, ustart);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 

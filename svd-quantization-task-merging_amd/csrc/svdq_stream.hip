@@ -220,11 +220,10 @@ __device__ __forceinline__ void load_block_gather(f32x4 (&v)[NTP], gfloat *(&bp)
     }
 }
 
-// Row mean over the NT real tasks (sum in task order, then one fp32 divide: basis.py:109),
-// subtract (basis.py:111), and park the centred strip in LDS.  Padded tasks are stored as 0.
-// STRIDED (gather mode): component e of a lane's vector is row 64 e + lane, not 4 lane + e.
-template <int NTP, bool STRIDED = false>
-__device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int center, float *X, int lane) {
+// Row mean over the NT real tasks (sum in task order, then one fp32 divide: basis.py:109).  Component-wise over the
+// lane's four rows, whichever rows those are.
+template <int NTP>
+__device__ __forceinline__ f32x4 row_mean(const f32x4 (&v)[NTP], int NT, int center) {
     f32x4 s = zero4();
     if constexpr (NTP > 16) {
         // same association as the two-wave pass 2 (each wave sums half of the tasks, then h0 + h1): pass 1 and
@@ -255,6 +254,14 @@ __device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int
         mean.z = s.z / n;
         mean.w = s.w / n;
     }
+    return mean;
+}
+
+// Subtract the row mean (basis.py:111) and park the centred strip in LDS.  Padded tasks are stored as 0.
+// STRIDED (gather mode): component e of a lane's vector is row 64 e + lane, not 4 lane + e.
+template <int NTP, bool STRIDED = false>
+__device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int center, float *X, int lane) {
+    const f32x4 mean = row_mean<NTP>(v, NT, center);
 #pragma unroll
     for (int t = 0; t < NTP; ++t) {
         f32x4 xc = (t < NT) ? (v[t] - mean) : zero4();
@@ -266,6 +273,120 @@ __device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int
         }
     }
     return mean;
+}
+
+// ------------------------------------------------------------------------------------ walk mode (masked parameters)
+// MODE bit 2.  Masked parameters WITHOUT index lists (reference mask_loader.py:651-709 applied inside the passes):
+// a unit still owns a run of 256-row blocks of the COMPACTED row space -- so every artifact bit is where the
+// compacted / gather modes put it -- but it reaches them by walking the SOURCE tensor from the position of its first
+// selected element (ustart[unit], found once per mask by svdq_maskset_*_starts from the tile scan):
+//   * chunk = 256 consecutive source rows; lane l owns rows src + 64 e + l (e = 0..3), so every dword load of a task
+//     reads 256 contiguous bytes and every mask load 64 contiguous bytes -- 4 N + 1 bytes per source row and pass,
+//     nothing per selected row (the index lists cost 4 bytes per selected row and pass on top of the rows themselves);
+//   * the four ballots of "row selected" give every selected row its rank in the chunk (s_bcnt / v_mbcnt, no scan
+//     through LDS); rank + rows already in the strip = its row in the current block;
+//   * centred values are scattered into the strip with ds_write_b32 -- consecutive lanes hold consecutive selected
+//     rows, so the writes are conflict-free; rows that overflow the block wait in registers until the block has been
+//     consumed (phase B below) and then open the next one.
+// Loads past the unit's last source row (the next unit's start, or the end of the tensor) are masked off, so
+// neighbouring units do not fetch each other's rows beyond the sector they share.
+typedef const __attribute__((address_space(1))) uint8_t gbyte;
+#define SVDQ_WALK_INV (1ll << 62)      // ustart[u] bit 62: select the CLEARED mask elements (the noise region)
+
+__device__ __forceinline__ int lanes_below(unsigned long long bal) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+}
+
+struct WalkSel {
+    bool sel[4];   // this lane's row e is selected
+    int pos[4];    // its row in the strip, counted from the start of the current block (may be >= 256)
+    int total;     // rows in the strip once the chunk is in (wave-uniform)
+};
+
+// the chunk's data: row src + 64 e + lane of every task (and of the base tensor, minus-base mode) + the mask bytes
+template <int NTP, bool SUB>
+__device__ __forceinline__ void walk_load(f32x4 (&v)[NTP], f32x4 &vb, unsigned (&mk)[4], gfloat *(&bp)[NTP],
+                                          gfloat *gbase, gbyte *gmask, int64_t src, int64_t src_end, int lane) {
+    const int64_t r = src + lane;
+    if (src + SVDQ_BLK_ROWS <= src_end) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mk[e] = gmask[r + 64 * e];
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+            f32x4 o;
+            o.x = bp[t][r];
+            o.y = bp[t][r + 64];
+            o.z = bp[t][r + 128];
+            o.w = bp[t][r + 192];
+            v[t] = o;
+        }
+        if constexpr (SUB) {
+            vb.x = gbase[r];
+            vb.y = gbase[r + 64];
+            vb.z = gbase[r + 128];
+            vb.w = gbase[r + 192];
+        }
+    } else {
+        bool in[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            in[e] = r + 64 * e < src_end;
+            mk[e] = in[e] ? (unsigned)gmask[r + 64 * e] : 0x100u;   // 0x100: past the end, selected by neither polarity
+        }
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+            f32x4 o = zero4();
+            if (in[0]) o.x = bp[t][r];
+            if (in[1]) o.y = bp[t][r + 64];
+            if (in[2]) o.z = bp[t][r + 128];
+            if (in[3]) o.w = bp[t][r + 192];
+            v[t] = o;
+        }
+        if constexpr (SUB) {
+            vb = zero4();
+            if (in[0]) vb.x = gbase[r];
+            if (in[1]) vb.y = gbase[r + 64];
+            if (in[2]) vb.z = gbase[r + 128];
+            if (in[3]) vb.w = gbase[r + 192];
+        }
+    }
+}
+
+// ranks of the chunk's selected rows (ascending source position = e-major, lane-minor)
+__device__ __forceinline__ WalkSel walk_select(const unsigned (&mk)[4], int inv, int fill) {
+    WalkSel w;
+    int base = fill;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        w.sel[e] = inv ? (mk[e] == 0u) : (mk[e] != 0u && mk[e] != 0x100u);
+        const unsigned long long bal = __ballot(w.sel[e]);
+        w.pos[e] = base + lanes_below(bal);
+        base += (int)__popcll(bal);
+    }
+    w.total = base;
+    return w;
+}
+
+// strip rows [lo, lo + 256) of the chunk: phase A (lo = 0) completes the current block, phase B (lo = 256) opens the next
+template <int NTP>
+__device__ __forceinline__ void walk_scatter(float *X, const f32x4 (&xc)[NTP], const WalkSel &w, int lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int q = w.pos[e] - lo;
+        if (w.sel[e] && (unsigned)q < (unsigned)SVDQ_BLK_ROWS) {
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) X[t * XS + q] = xc[t][e];
+        }
+    }
+}
+
+// rows [fill, 256) of the strip <- 0 (the last, partial block of a parameter)
+template <int NTP>
+__device__ __forceinline__ void walk_zero_tail(float *X, int fill, int lane) {
+    for (int q = fill + lane; q < SVDQ_BLK_ROWS; q += 64) {
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) X[t * XS + q] = 0.f;
+    }
 }
 
 // ------------------------------------------------------------------------------------ pass 1
@@ -285,8 +406,10 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
                                           double *__restrict__ gram_part,
                                           const void *const *__restrict__ aux = nullptr,
                                           const int32_t *__restrict__ only = nullptr,
-                                          const void *const *__restrict__ aux2 = nullptr) {
-    constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0;
+                                          const void *const *__restrict__ aux2 = nullptr,
+                                          const int64_t *__restrict__ ustart = nullptr) {
+    constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0, WALK = (MODE & 4) != 0;
+    static_assert(!(GATHER && WALK), "index lists and the mask walk are alternatives");
     static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
@@ -380,7 +503,9 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     gfloat *gbase = nullptr;
     f32x4 vb = zero4();  // base rows of the block whose fine-tuned rows sit in v
     if constexpr (SUB) gbase = (gfloat *)aux2[p];
-    if constexpr (GATHER) {
+    if constexpr (WALK) {
+        // loads are issued by the walk loop below
+    } else if constexpr (GATHER) {
         gidx = (gint *)aux[p];
         if (r_begin < r_end) {
             const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
@@ -399,24 +524,8 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     if (r_begin + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v1, bp, r_begin + SVDQ_BLK_ROWS, D, lane);
 #endif
 
-    auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
-        if constexpr (SUB) {
-#pragma unroll
-            for (int t = 0; t < NTP; ++t) v[t] = v[t] - vb;
-        }
-        center_store<NTP, GATHER>(v, NT, center, X, lane);
-        wave_sync();
-        if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
-            if constexpr (GATHER) {
-                load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
-                if constexpr (SUB) vb = load_base_gather(gbase, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
-                if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
-            } else {
-                load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
-                if constexpr (SUB) vb = load_base(gbase, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
-            }
-        }
-
+    // the MFMA phase over the strip of one block (ends with the barrier that frees the strip)
+    auto compute = [&]() {
         f32x4 acc[NACC];
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = zero4();
@@ -554,11 +663,81 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
         wave_sync();
     };
 
-    for (int64_t rb = r_begin; rb < r_end; rb += AHEAD * SVDQ_BLK_ROWS) {
-        do_block(v0, rb);
+    if constexpr (WALK) {
+        // walk the source rows from this unit's first selected element (see "walk mode" above)
+        gbyte *gmask = (gbyte *)aux[p];
+        const int64_t Dsrc = params[p].rows;
+        const int64_t us = ustart[uidx];
+        const int inv = (us & SVDQ_WALK_INV) ? 1 : 0;
+        int64_t src = us & (SVDQ_WALK_INV - 1);
+        int64_t src_end = Dsrc;      // where the next unit's rows begin
+        if (uidx + 1 < params[p].unit_begin + params[p].unit_count) src_end = ustart[uidx + 1] & (SVDQ_WALK_INV - 1);
+        if (src_end > Dsrc) src_end = Dsrc;
+        const int need = (r_begin < r_end) ? (int)(r_end - r_begin) : 0;
+        int produced = 0, fill = 0;
+        unsigned mk[4];
+        bool have = need > 0 && src < src_end;
+        if (have) walk_load<NTP, SUB>(v0, vb, mk, bp, gbase, gmask, src, src_end, lane);
+        bool more = need > 0;
+        while (more) {
+            const int fill0 = fill;
+            WalkSel w;
+            w.total = SVDQ_BLK_ROWS;      // no chunk left: flush the partial block
+            if (have) {
+                w = walk_select(mk, inv, fill0);
+                if constexpr (SUB) {
+#pragma unroll
+                    for (int t = 0; t < NTP; ++t) v0[t] = v0[t] - vb;
+                }
+                const f32x4 mean = row_mean<NTP>(v0, NT, center);
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) v0[t] = (t < NT) ? (v0[t] - mean) : zero4();
+                walk_scatter<NTP>(X, v0, w, 0);
+            } else {
+                walk_zero_tail<NTP>(X, fill0, lane);
+            }
+            if (w.total >= SVDQ_BLK_ROWS) {
+                wave_sync();
+                compute();
+                if (have) walk_scatter<NTP>(X, v0, w, SVDQ_BLK_ROWS);
+                fill = have ? w.total - SVDQ_BLK_ROWS : 0;
+            } else {
+                fill = w.total;
+            }
+            if (have) {
+                produced += w.total - fill0;
+                src += SVDQ_BLK_ROWS;
+            }
+            have = have && produced < need && src < src_end;
+            if (have) walk_load<NTP, SUB>(v0, vb, mk, bp, gbase, gmask, src, src_end, lane);
+            more = have || fill > 0;
+        }
+    } else {
+        auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
+            if constexpr (SUB) {
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) v[t] = v[t] - vb;
+            }
+            center_store<NTP, GATHER>(v, NT, center, X, lane);
+            wave_sync();
+            if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
+                if constexpr (GATHER) {
+                    load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
+                    if constexpr (SUB) vb = load_base_gather(gbase, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
+                    if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
+                } else {
+                    load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
+                    if constexpr (SUB) vb = load_base(gbase, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
+                }
+            }
+            compute();
+        };
+        for (int64_t rb = r_begin; rb < r_end; rb += AHEAD * SVDQ_BLK_ROWS) {
+            do_block(v0, rb);
 #if SVDQ_PREFETCH2
-        if (rb + SVDQ_BLK_ROWS < r_end) do_block(v1, rb + SVDQ_BLK_ROWS);
+            if (rb + SVDQ_BLK_ROWS < r_end) do_block(v1, rb + SVDQ_BLK_ROWS);
 #endif
+        }
     }
     if constexpr (F64) {
 #pragma unroll
@@ -663,17 +842,18 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
 #define SVDQ_GRAM64_WAVES16 3
 #endif
 template <int NTP, int MODE, bool F64>
-__global__ __launch_bounds__(64, (F64 && MODE == 0 && NTP <= 16) ? (NTP <= 8 ? SVDQ_GRAM64_WAVES8 : SVDQ_GRAM64_WAVES16) : 1) void k_gram(const SvdqParam *__restrict__ params,
+__global__ __launch_bounds__(64, (F64 && (MODE == 0 || MODE == 4) && NTP <= 16) ? (NTP <= 8 ? SVDQ_GRAM64_WAVES8 : SVDQ_GRAM64_WAVES16) : 1) void k_gram(const SvdqParam *__restrict__ params,
                                              const SvdqUnit *__restrict__ units,
                                              const float *const *__restrict__ ptrs,
                                              const int64_t *__restrict__ rows_dev, int NT, int center,
                                              double *__restrict__ gram_part, int unit0,
                                              const void *const *__restrict__ aux,
                                              const int32_t *__restrict__ only,
-                                             const void *const *__restrict__ aux2, int order) {
+                                             const void *const *__restrict__ aux2, int order,
+                                             const int64_t *__restrict__ ustart) {
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
     gram_unit<NTP, MODE, F64>(X, unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, order), params, units, ptrs,
-                              rows_dev, NT, center, gram_part, aux, only, aux2);
+                              rows_dev, NT, center, gram_part, aux, only, aux2, ustart);
 }
 
 // ------------------------------------------------------------------------------------ pass 2
@@ -728,8 +908,9 @@ __device__ __forceinline__ void bp_unit(
     const int64_t *__restrict__ rows_dev, int NT, int center, const float *__restrict__ Wtab,
     const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev, uint8_t *__restrict__ basis,
     float *__restrict__ meanbuf, double *__restrict__ cpart, const void *const *__restrict__ aux = nullptr,
-    const void *const *__restrict__ aux2 = nullptr) {
-    constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0;
+    const void *const *__restrict__ aux2 = nullptr, const int64_t *__restrict__ ustart = nullptr) {
+    constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0, WALK = (MODE & 4) != 0;
+    static_assert(!(GATHER && WALK), "index lists and the mask walk are alternatives");
     static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
@@ -816,7 +997,9 @@ __device__ __forceinline__ void bp_unit(
     gfloat *gbase = nullptr;
     f32x4 vb = zero4();  // base rows of the block whose fine-tuned rows sit in v
     if constexpr (SUB) gbase = (gfloat *)aux2[p];
-    if constexpr (GATHER) {
+    if constexpr (WALK) {
+        // loads are issued by the walk loop below
+    } else if constexpr (GATHER) {
         gidx = (gint *)aux[p];
         if (r_begin < r_end) {
             const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
@@ -835,44 +1018,8 @@ __device__ __forceinline__ void bp_unit(
     if (r_begin + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v1, bp, r_begin + SVDQ_BLK_ROWS, D, lane);
 #endif
 
-    auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
-        if constexpr (SUB) {
-#pragma unroll
-            for (int t = 0; t < NTP; ++t) v[t] = v[t] - vb;
-        }
-        const f32x4 mean = center_store<NTP, GATHER>(v, NT, center, X, lane);
-#ifdef SVDQ_ABLATE_STORES
-        if (gmean && D < 0) {
-#else
-        if (gmean) {
-#endif
-            if constexpr (GATHER) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (rb + 64 * e + lane < D) gmean[rb + 64 * e + lane] = mean[e];
-            } else {
-                const int64_t rr = rb + 4 * lane;
-                if (rr + 3 < D) {
-                    *reinterpret_cast<f32x4 *>(gmean + rr) = mean;
-                } else {
-                    if (rr < D) gmean[rr] = mean.x;
-                    if (rr + 1 < D) gmean[rr + 1] = mean.y;
-                    if (rr + 2 < D) gmean[rr + 2] = mean.z;
-                }
-            }
-        }
-        wave_sync();
-        if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
-            if constexpr (GATHER) {
-                load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
-                if constexpr (SUB) vb = load_base_gather(gbase, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
-                if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
-            } else {
-                load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
-                if constexpr (SUB) vb = load_base(gbase, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
-            }
-        }
-
+    // one block out of the strip: U tiles, fp16 staging, rounding-correction MFMAs, the two row-major stores
+    auto compute = [&](int64_t rb) {
         f32x4 cf[NCB];
 #pragma unroll
         for (int i = 0; i < NCB; ++i) cf[i] = zero4();
@@ -969,11 +1116,109 @@ UNROLL_N(SVDQ_UNROLL_BP)
         wave_sync();
     };
 
-    for (int64_t rb = r_begin; rb < r_end; rb += AHEAD * SVDQ_BLK_ROWS) {
-        do_block(v0, rb);
-#if SVDQ_PREFETCH2
-        if (rb + SVDQ_BLK_ROWS < r_end) do_block(v1, rb + SVDQ_BLK_ROWS);
+    if constexpr (WALK) {
+        // walk the source rows from this unit's first selected element (see "walk mode" above)
+        gbyte *gmask = (gbyte *)aux[p];
+        const int64_t Dsrc = params[p].rows;
+        const int64_t us = ustart[uidx];
+        const int inv = (us & SVDQ_WALK_INV) ? 1 : 0;
+        int64_t src = us & (SVDQ_WALK_INV - 1);
+        int64_t src_end = Dsrc;      // where the next unit's rows begin
+        if (uidx + 1 < params[p].unit_begin + params[p].unit_count) src_end = ustart[uidx + 1] & (SVDQ_WALK_INV - 1);
+        if (src_end > Dsrc) src_end = Dsrc;
+        const int need = (r_begin < r_end) ? (int)(r_end - r_begin) : 0;
+        int produced = 0, fill = 0;
+        int64_t rb = r_begin;
+        unsigned mk[4];
+        bool have = need > 0 && src < src_end;
+        if (have) walk_load<NTP, SUB>(v0, vb, mk, bp, gbase, gmask, src, src_end, lane);
+        bool more = need > 0;
+        while (more) {
+            const int fill0 = fill;
+            WalkSel w;
+            w.total = SVDQ_BLK_ROWS;      // no chunk left: flush the partial block
+            if (have) {
+                w = walk_select(mk, inv, fill0);
+                if constexpr (SUB) {
+#pragma unroll
+                    for (int t = 0; t < NTP; ++t) v0[t] = v0[t] - vb;
+                }
+                const f32x4 mean = row_mean<NTP>(v0, NT, center);
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) v0[t] = (t < NT) ? (v0[t] - mean) : zero4();
+                if (gmean) {   // mean of the compacted rows: consecutive lanes, consecutive rows
+                    const int64_t m0 = rb - fill0;      // compacted row of strip position 0
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (w.sel[e] && m0 + w.pos[e] < D) gmean[m0 + w.pos[e]] = mean[e];
+                }
+                walk_scatter<NTP>(X, v0, w, 0);
+            } else {
+                walk_zero_tail<NTP>(X, fill0, lane);
+            }
+            if (w.total >= SVDQ_BLK_ROWS) {
+                wave_sync();
+                compute(rb);
+                rb += SVDQ_BLK_ROWS;
+                if (have) walk_scatter<NTP>(X, v0, w, SVDQ_BLK_ROWS);
+                fill = have ? w.total - SVDQ_BLK_ROWS : 0;
+            } else {
+                fill = w.total;
+            }
+            if (have) {
+                produced += w.total - fill0;
+                src += SVDQ_BLK_ROWS;
+            }
+            have = have && produced < need && src < src_end;
+            if (have) walk_load<NTP, SUB>(v0, vb, mk, bp, gbase, gmask, src, src_end, lane);
+            more = have || fill > 0;
+        }
+    } else {
+        auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
+            if constexpr (SUB) {
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) v[t] = v[t] - vb;
+            }
+            const f32x4 mean = center_store<NTP, GATHER>(v, NT, center, X, lane);
+#ifdef SVDQ_ABLATE_STORES
+            if (gmean && D < 0) {
+#else
+            if (gmean) {
 #endif
+                if constexpr (GATHER) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (rb + 64 * e + lane < D) gmean[rb + 64 * e + lane] = mean[e];
+                } else {
+                    const int64_t rr = rb + 4 * lane;
+                    if (rr + 3 < D) {
+                        *reinterpret_cast<f32x4 *>(gmean + rr) = mean;
+                    } else {
+                        if (rr < D) gmean[rr] = mean.x;
+                        if (rr + 1 < D) gmean[rr + 1] = mean.y;
+                        if (rr + 2 < D) gmean[rr + 2] = mean.z;
+                    }
+                }
+            }
+            wave_sync();
+            if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
+                if constexpr (GATHER) {
+                    load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
+                    if constexpr (SUB) vb = load_base_gather(gbase, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
+                    if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
+                } else {
+                    load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
+                    if constexpr (SUB) vb = load_base(gbase, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
+                }
+            }
+            compute(rb);
+        };
+        for (int64_t rb = r_begin; rb < r_end; rb += AHEAD * SVDQ_BLK_ROWS) {
+            do_block(v0, rb);
+#if SVDQ_PREFETCH2
+            if (rb + SVDQ_BLK_ROWS < r_end) do_block(v1, rb + SVDQ_BLK_ROWS);
+#endif
+        }
     }
 
     // rounding-correction partials: cpart[slot][t*NT + i]; lane (c,g) holds D[m = U column][n = task]
@@ -1007,13 +1252,13 @@ __global__ __launch_bounds__(64) void k_basis_project(
     const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
     const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
     uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse,
-    const void *const *__restrict__ aux, const void *const *__restrict__ aux2) {
+    const void *const *__restrict__ aux, const void *const *__restrict__ aux2, const int64_t *__restrict__ ustart) {
     using out_t = typename OutT<OUT16>::type;
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
     __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];  // +16: dump slot for idle lanes
     const int uidx = unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, reverse);
     bp_unit<NTP, OUT16, MODE>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis,
-                              meanbuf, cpart, aux, aux2);
+                              meanbuf, cpart, aux, aux2, ustart);
 }
 
 // ------------------------------------------------------------------------------------ N > 16: two waves
@@ -1627,17 +1872,33 @@ __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
 
 // ------------------------------------------------------------------------------------ launchers
 // idx: NULL or the device table of index lists (gather mode); base: NULL or the device table of base tensors
-// (minus-base mode); both may be given (masked parameters straight from checkpoints).
+// (minus-base mode); both may be given (masked parameters straight from checkpoints).  ustart: NULL, or the per-unit
+// source start positions of the walk mode -- idx is then the device table of combined MASK byte tensors.
 template <int NTP>
 static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
                          int unit0, int nunits, int center, const void *idx, const void *base, int f64,
-                         const int32_t *only, hipStream_t st) {
+                         const int32_t *only, const int64_t *ustart, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
     auto ai = (const void *const *)idx, ab = (const void *const *)base;
 #define SVDQ_LAUNCH_GRAM(M, F)                                                                                       \
     hipLaunchKernelGGL((k_gram<NTP, M, F>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, rows_dev, \
-                       pl->n_tasks, center, gram_part, unit0, ai, only, ab, pl->cfg.reserved & 4)
-    const int mode = (idx ? 1 : 0) | (base ? 2 : 0);
+                       pl->n_tasks, center, gram_part, unit0, ai, only, ab, pl->cfg.reserved & 4, ustart)
+    const int mode = ustart ? (4 | (base ? 2 : 0)) : ((idx ? 1 : 0) | (base ? 2 : 0));
+    if constexpr (NTP <= 16) {
+        if (mode & 4) {      // walk mode exists for the one-wave kernels (N <= 16), always with the default Gram
+            if (f64) {
+                if (mode == 4) SVDQ_LAUNCH_GRAM(4, true); else SVDQ_LAUNCH_GRAM(6, true);
+            } else {
+                if (mode == 4) SVDQ_LAUNCH_GRAM(4, false); else SVDQ_LAUNCH_GRAM(6, false);
+            }
+            return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+        }
+    }
+    if (mode & 4) {
+        svdq_set_error("the mask-walk mode covers N <= 16 tasks (got %d): use the index lists (svdq_compress_gather)",
+                       pl->n_tasks);
+        return SVDQ_EUNSUPPORTED;
+    }
     if (f64) {
         switch (mode) {
             case 0: SVDQ_LAUNCH_GRAM(0, true); break;
@@ -1661,9 +1922,9 @@ static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *r
 // table [n_params] -- units of parameters whose entry is 0 return at once (the refinement pass of N > 16)
 int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
                      int unit0, int nunits, int center, const void *idx, const void *base, int f64,
-                     const int32_t *only, hipStream_t st) {
+                     const int32_t *only, hipStream_t st, const int64_t *ustart) {
 #define SVDQ_GRAM_CASE(n) \
-    case n: return launch_gram_t<n>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, f64, only, st)
+    case n: return launch_gram_t<n>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, f64, only, ustart, st)
     switch (pl->ntp) {
         SVDQ_GRAM_CASE(4); SVDQ_GRAM_CASE(8); SVDQ_GRAM_CASE(12); SVDQ_GRAM_CASE(16);
         SVDQ_GRAM_CASE(20); SVDQ_GRAM_CASE(24); SVDQ_GRAM_CASE(28); SVDQ_GRAM_CASE(32);
@@ -1674,10 +1935,27 @@ int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
 }
 
 template <int NTP, bool F16>
-static void launch_bp_mode(const svdq_plan *pl, const float *const *pp, const int64_t *rows_dev, const float *W,
-                           const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
-                           int unit0, int nunits, int reverse, const void *idx, const void *base, hipStream_t st) {
+static int launch_bp_mode(const svdq_plan *pl, const float *const *pp, const int64_t *rows_dev, const float *W,
+                          const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
+                          int unit0, int nunits, int reverse, const void *idx, const void *base,
+                          const int64_t *ustart, hipStream_t st) {
     auto ai = (const void *const *)idx, ab = (const void *const *)base;
+    if (ustart) {
+        if constexpr (NTP <= 16) {
+            if (base)
+                hipLaunchKernelGGL((k_basis_project<NTP, F16, 6>), dim3(nunits), dim3(64), 0, st, pl->d_params,
+                                   pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,
+                                   cpart, unit0, reverse, ai, ab, ustart);
+            else
+                hipLaunchKernelGGL((k_basis_project<NTP, F16, 4>), dim3(nunits), dim3(64), 0, st, pl->d_params,
+                                   pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,
+                                   cpart, unit0, reverse, ai, ab, ustart);
+            return SVDQ_OK;
+        }
+        svdq_set_error("the mask-walk mode covers N <= 16 tasks (got %d): use the index lists (svdq_compress_gather)",
+                       pl->n_tasks);
+        return SVDQ_EUNSUPPORTED;
+    }
 #define SVDQ_LAUNCH_BP(M)                                                                                             \
     do {                                                                                                              \
         if constexpr (NTP == 20) {   /* N = 21..24: measured slower than the two-wave kernel (11.9 against 10.0 ms) */ \
@@ -1695,7 +1973,7 @@ static void launch_bp_mode(const svdq_plan *pl, const float *const *pp, const in
         else                                                                                                          \
             hipLaunchKernelGGL((k_basis_project<NTP, F16, M>), dim3(nunits), dim3(64), 0, st, pl->d_params,           \
                                pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
-                               cpart, unit0, reverse, ai, ab);                                                        \
+                               cpart, unit0, reverse, ai, ab, (const int64_t *)nullptr);                              \
     } while (0)
     switch ((idx ? 1 : 0) | (base ? 2 : 0)) {
         case 0: SVDQ_LAUNCH_BP(0); break;
@@ -1704,26 +1982,30 @@ static void launch_bp_mode(const svdq_plan *pl, const float *const *pp, const in
         default: SVDQ_LAUNCH_BP(3); break;
     }
 #undef SVDQ_LAUNCH_BP
+    return SVDQ_OK;
 }
 
 template <int NTP>
 static int launch_bp_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                        const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
-                       int unit0, int nunits, int reverse, const void *idx, const void *base, hipStream_t st) {
+                       int unit0, int nunits, int reverse, const void *idx, const void *base, const int64_t *ustart,
+                       hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
+    int rc;
     if (pl->cfg.fp16)
-        launch_bp_mode<NTP, true>(pl, pp, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+        rc = launch_bp_mode<NTP, true>(pl, pp, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, ustart, st);
     else
-        launch_bp_mode<NTP, false>(pl, pp, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st);
+        rc = launch_bp_mode<NTP, false>(pl, pp, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, ustart, st);
+    if (rc != SVDQ_OK) return rc;
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
 int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const float *W,
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
                               double *cpart, int unit0, int nunits, int reverse, const void *idx, const void *base,
-                              hipStream_t st) {
+                              hipStream_t st, const int64_t *ustart) {
 #define SVDQ_BP_CASE(n) \
-    case n: return launch_bp_t<n>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, st)
+    case n: return launch_bp_t<n>(pl, ptrs, rows_dev, W, k_dev, r_dev, basis, mean, cpart, unit0, nunits, reverse, idx, base, ustart, st)
     switch (pl->ntp) {
         SVDQ_BP_CASE(4); SVDQ_BP_CASE(8); SVDQ_BP_CASE(12); SVDQ_BP_CASE(16);
         SVDQ_BP_CASE(20); SVDQ_BP_CASE(24); SVDQ_BP_CASE(28); SVDQ_BP_CASE(32);

@@ -15,6 +15,12 @@ from . import mask_loader as ml
 
 
 
+# the mask-walk mode (svdq_compress_masked) serves regions that hold at least this share of their tensors' elements --
+# below it, skipping rows through index lists reads less than walking past them -- and the one-wave kernels (N <= 16)
+WALK_MIN_DENSITY = 0.5
+WALK_MAX_TASKS = 16
+
+
 def _resident(tensors, dev) -> bool:
     """All tensors already satisfy the ABI's input contract except (possibly) for their shape: fp32, contiguous, on
     ``dev``, 16-byte aligned -- then the plan can take their addresses as they are (pointer_table re-checks)."""
@@ -43,7 +49,7 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
     bits_by_param = getattr(config, "svd_low_bits_by_param", None)
 
     # group regions by the number of tasks that have the parameter (one plan per N)
-    groups: Dict[Tuple[int, bool], List[dict]] = {}   # (tasks present, gather mode) -> regions of one plan
+    groups: Dict[Tuple[int, str], List[dict]] = {}   # (tasks present, "plain" | "gather" | "walk") -> regions of one plan
     keep = []
     with torch.cuda.device(dev):
         masked_by_n: Dict[int, List[tuple]] = {}
@@ -61,33 +67,52 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
                     else [prepare_vector(d, dev) for d in deltas]
                 if vs[0].numel() == 0:
                     continue
-                groups.setdefault((len(present), False), []).append(
+                groups.setdefault((len(present), "plain"), []).append(
                     {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": None,
                      "upper": vs[0].numel(), "min": 0,
                      "base": prepare_vector(base_state[name], dev) if base_state is not None else None})
-        # every masked parameter of a group gets ONE batched index build (signal and, when asked, noise in the same
-        # pass): the compressor then reads the original task tensors through the index lists (gather mode), so no
-        # compacted copies of the deltas are ever written; mask.sum() stays on the device and becomes rows_dev
+        # Masked parameters never get compacted copies of their deltas.  One count + scan per group (mask.sum() stays
+        # on the device and becomes rows_dev); then, per region, one of two ways to reach the selected rows:
+        #   walk   (N <= 16 and the region holds at least half of the elements): both passes walk the source rows with
+        #          the mask byte beside them and compact in LDS (svdq_compress_masked) -- nothing is built per row;
+        #   gather (sparse regions, N > 16): int32 index lists, rows fetched through them (svdq_compress_gather).
         for n_present, items in masked_by_n.items():
-            ms = ml.MaskSet([it[3].numel() for it in items], dev)
-            it_, if_, ct, cf = ms.indices([it[3] for it in items], want_false=include_noise)
+            numels = [it[3].numel() for it in items]
+            ms = ml.MaskSet(numels, dev)
+            mask_list = [it[3] for it in items]
+            ct, cf = ms.count_scan(mask_list)
+            dens = float(ct.sum().item()) / float(max(sum(numels), 1))
+            can_walk = n_present <= WALK_MAX_TASKS
+            walk_sig = can_walk and dens >= WALK_MIN_DENSITY
+            walk_noise = can_walk and include_noise and (1.0 - dens) >= WALK_MIN_DENSITY
+            it_ = if_ = None
+            if not walk_sig or (include_noise and not walk_noise):
+                it_, if_, _, _ = ms.indices(mask_list, want_false=include_noise and not walk_noise)
             keep.append((ms, it_, if_))
             for q, (name, present, deltas, _) in enumerate(items):
                 vs = [prepare_vector(d, dev) for d in deltas]
                 bvec = prepare_vector(base_state[name], dev) if base_state is not None else None
-                groups.setdefault((n_present, True), []).append(
-                    {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": ct[q:q + 1],
-                     "upper": vs[0].numel(), "min": min_size, "index": it_[q], "base": bvec})
+                e = {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": ct[q:q + 1],
+                     "upper": vs[0].numel(), "min": min_size, "base": bvec}
+                if walk_sig:
+                    e.update(ms=ms, q=q, inv=False)
+                else:
+                    e["index"] = it_[q]
+                groups.setdefault((n_present, "walk" if walk_sig else "gather"), []).append(e)
                 if include_noise:
-                    groups.setdefault((n_present, True), []).append(
-                        {"name": name, "region": "noise", "tasks": present, "vectors": vs, "count": cf[q:q + 1],
-                         "upper": vs[0].numel(), "min": 1, "gate": ct[q:q + 1], "index": if_[q], "base": bvec})
+                    e = {"name": name, "region": "noise", "tasks": present, "vectors": vs, "count": cf[q:q + 1],
+                         "upper": vs[0].numel(), "min": 1, "gate": ct[q:q + 1], "base": bvec}
+                    if walk_noise:
+                        e.update(ms=ms, q=q, inv=True)
+                    else:
+                        e["index"] = if_[q]
+                    groups.setdefault((n_present, "walk" if walk_noise else "gather"), []).append(e)
         order = {n: i for i, n in enumerate(names)}
         for lst in groups.values():
             lst.sort(key=lambda e: (order[e["name"]], e["region"] != "masked"))
 
         bases: Dict[str, Dict] = {}
-        for (n_tasks, gather), entries in groups.items():
+        for (n_tasks, mode), entries in groups.items():
             entries = [e for e in entries if e["upper"] > 0]
             if not entries:
                 continue
@@ -112,17 +137,26 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
                         parts.append(torch.where(ok, c, torch.zeros_like(c)))
                 rows_dev = torch.cat(parts)
             table = plan.pointer_table([e["vectors"] for e in entries])
-            if gather and base_state is not None:
-                itab = torch.tensor([e["index"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
+            btab = None
+            if base_state is not None:
                 btab = torch.tensor([e["base"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
                 keep.append([e["base"] for e in entries])
-                plan.run_gather_from_base(table, btab, itab, rows_dev)
-            elif gather:
+            if mode == "walk":
+                ms = entries[0]["ms"]
+                mtab = torch.tensor([ms._s["mb"][e["q"]].data_ptr() for e in entries], dtype=torch.int64).to(dev)
+                us = ms.unit_starts(plan, rows_dev, entry_map=[(e["q"], e["inv"]) for e in entries], mask_table=mtab)
+                keep.append((mtab, us))
+                if btab is not None:
+                    plan.run_masked_from_base(table, btab, mtab, us, rows_dev)
+                else:
+                    plan.run_masked(table, mtab, us, rows_dev)
+            elif mode == "gather":
                 itab = torch.tensor([e["index"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
-                plan.run_gather(table, itab, rows_dev)
-            elif base_state is not None:
-                btab = torch.tensor([e["base"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
-                keep.append([e["base"] for e in entries])
+                if btab is not None:
+                    plan.run_gather_from_base(table, btab, itab, rows_dev)
+                else:
+                    plan.run_gather(table, itab, rows_dev)
+            elif btab is not None:
                 plan.run_from_base(table, btab, rows_dev)
             else:
                 plan.run(table, rows_dev)

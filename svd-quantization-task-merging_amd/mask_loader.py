@@ -176,6 +176,87 @@ class MaskSet:
                 _ptr(x["ft"]), _ptr(x["ct"]), _ptr(x["cf"]), _ptr(self.work), _stream_ptr()),
                 "svdq_maskset_combine_packed_indices")
 
+    # ---- unit starts: what the mask-walk mode of the compressor (CompressPlan.run_masked) needs instead of index lists
+    def count_scan(self, masks):
+        """mask.sum() / (~mask).sum() of already combined masks (device int64 [Q] each); leaves the tile offsets in
+        ``self.work`` for unit_starts()."""
+        mb = [_as_mask_bytes(m, self.device) for m in masks]
+        for q in range(self.Q):
+            if mb[q].numel() != self.numels[q]:
+                raise ValueError(f"Shape mismatch: tensor vs mask for parameter {q}")
+        ct = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        cf = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        self._s = dict(mb=mb, mt=self._table(mb), ct=ct, cf=cf)
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_count_scan(self._h, _ptr(self._s["mt"]), _ptr(ct), _ptr(cf), _ptr(self.work),
+                                                       _stream_ptr()), "svdq_maskset_count_scan")
+        return ct, cf
+
+    def unit_starts(self, plan, rows_dev, entry_map=None, mask_table=None) -> torch.Tensor:
+        """Source position of every work unit's first row (device int64 [plan units]) for the masks counted last
+        (count_scan / run_combine / ...).  ``entry_map``: None (plan parameter p <-> mask p) or a list of
+        (mask index, inverted) per plan parameter -- the noise region takes the cleared elements of its mask."""
+        mt = mask_table if mask_table is not None else self._s["mt"]
+        em = None
+        if entry_map is not None:
+            # bit 31 = inverted: as a signed int32 that is q - 2^31
+            em = torch.tensor([int(q) - (1 << 31) if inv else int(q) for q, inv in entry_map],
+                              dtype=torch.int32).to(self.device)
+        us = torch.empty(int(plan.sizes.n_units), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_unit_starts(self._h, plan._h, _ptr(mt), _ptr(em), _ptr(rows_dev),
+                                                        _ptr(self.work), _ptr(us), _stream_ptr()),
+                      "svdq_maskset_unit_starts")
+        return us
+
+    def prepare_combine_starts(self, masks_per_param, strategy: str, plan):
+        """combine + scan + unit starts in 3 launches (no index lists); run with run_combine_starts().
+        Returns (combined uint8 masks, count_true [Q], unit starts [plan units])."""
+        outs, _ = self.prepare_combine(masks_per_param, strategy)
+        ct = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        cf = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        us = torch.empty(int(plan.sizes.n_units), dtype=torch.int64, device=self.device)
+        self._cs = dict(ct=ct, cf=cf, us=us, plan=plan)
+        self._s = dict(mb=outs, mt=self._c["ot"], ct=ct, cf=cf)
+        return outs, ct, us
+
+    def run_combine_starts(self):
+        c, x = self._c, self._cs
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_combine_starts(self._h, x["plan"]._h, _ptr(c["mt"]), c["n"], c["strategy"],
+                                                           _ptr(c["ot"]), _ptr(x["ct"]), _ptr(x["cf"]), _ptr(self.work),
+                                                           _ptr(x["us"]), _stream_ptr()), "svdq_maskset_combine_starts")
+
+    def prepare_combine_packed_starts(self, streams, bit_offsets, strategy: str, plan):
+        """The same from bit-packed tall masks (see prepare_combine_packed_indices)."""
+        if strategy not in nat.MASK_STRATEGIES:
+            raise ValueError(f"Unknown mask strategy: {strategy}")
+        if not streams:
+            raise ValueError("Empty mask list")
+        st = [s.to(self.device).contiguous().view(torch.uint8) for s in streams]
+        need = max((int(o) + n + 7) // 8 for o, n in zip(bit_offsets, self.numels))
+        if any(s.numel() < need for s in st):
+            raise ValueError("Shape mismatch: a packed mask stream is shorter than the parameters it should cover")
+        outs = [torch.empty(nq, dtype=torch.uint8, device=self.device) for nq in self.numels]
+        ct = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        cf = torch.zeros(self.Q, dtype=torch.int64, device=self.device)
+        us = torch.empty(int(plan.sizes.n_units), dtype=torch.int64, device=self.device)
+        self._ps = dict(st=st, outs=outs, ct=ct, cf=cf, us=us, plan=plan, n=len(st),
+                        strategy=nat.MASK_STRATEGIES[strategy], sp=self._table(st),
+                        sb=torch.tensor([s.numel() for s in st], dtype=torch.int64).to(self.device),
+                        bo=torch.tensor([int(o) for o in bit_offsets], dtype=torch.int64).to(self.device),
+                        ot=self._table(outs))
+        self._s = dict(mb=outs, mt=self._ps["ot"], ct=ct, cf=cf)
+        return outs, ct, us
+
+    def run_combine_packed_starts(self):
+        x = self._ps
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.svdq_maskset_combine_packed_starts(
+                self._h, x["plan"]._h, _ptr(x["sp"]), _ptr(x["sb"]), _ptr(x["bo"]), x["n"], x["strategy"], _ptr(x["ot"]),
+                _ptr(x["ct"]), _ptr(x["cf"]), _ptr(self.work), _ptr(x["us"]), _stream_ptr()),
+                "svdq_maskset_combine_packed_starts")
+
     def indices(self, masks, want_false: bool):
         """Ascending flat positions (int32) of the set / cleared elements of every mask: what the gather mode
         of the compressor reads the task deltas through, instead of 2 N compacted copies per parameter.

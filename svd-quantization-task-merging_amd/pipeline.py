@@ -243,6 +243,24 @@ class CompressPlan:
                                                 _ptr(self.workspace), _ptr(self.small), _ptr(self.basis),
                                                 _ptr(self.mean), _stream_ptr()), "svdq_compress_gather")
 
+    def run_masked(self, table, mask_table, unit_start, rows_dev):
+        """run() for masked parameters without index lists: ``table`` names the ORIGINAL full-size task tensors,
+        ``mask_table`` (device int64 [P]) the combined bool-byte masks, ``unit_start`` the source position of every
+        work unit's first row (MaskSet.unit_starts / run_combine_starts), ``rows_dev`` the selected-row counts.
+        Both passes walk the source rows and compact them in LDS (N <= 16)."""
+        nat.check(self.lib.svdq_compress_masked(self._h, _ptr(table), _ptr(mask_table), _ptr(unit_start),
+                                                _ptr(rows_dev), _ptr(self.workspace), _ptr(self.small),
+                                                _ptr(self.basis), _ptr(self.mean), _stream_ptr()),
+                  "svdq_compress_masked")
+
+    def run_masked_from_base(self, finetuned_table, base_table, mask_table, unit_start, rows_dev):
+        """run_masked() straight from checkpoints (finetuned[row] - base[row] formed inside the passes)."""
+        nat.check(self.lib.svdq_compress_masked_from_base(self._h, _ptr(finetuned_table), _ptr(base_table),
+                                                          _ptr(mask_table), _ptr(unit_start), _ptr(rows_dev),
+                                                          _ptr(self.workspace), _ptr(self.small), _ptr(self.basis),
+                                                          _ptr(self.mean), _stream_ptr()),
+                  "svdq_compress_masked_from_base")
+
     def run_from_base(self, finetuned_table, base_table, rows_dev=None):
         """run() straight from checkpoints: ``finetuned_table`` [P*N] names the fine-tuned tensors, ``base_table``
         [P] the base model's; finetuned - base is formed inside the streaming passes (no task vectors in HBM)."""

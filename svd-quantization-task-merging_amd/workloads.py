@@ -49,26 +49,36 @@ def numel(shape) -> int:
 def synth_task_buffers(rows: List[int], n_tasks: int, seed: int, device, rank: int = 3, a: float = 0.01,
                        eps: float = 0.002) -> Tuple[List[torch.Tensor], List[List[torch.Tensor]]]:
     """One flat fp32 buffer per task holding every parameter (64-float aligned offsets), filled on
-    the device with delta_t = a * B (g_t * s) + eps * n_t, s = (1, .5, .25, ...).
-    Returns (task buffers, views[p][t])."""
+    the device with delta_t = a * B (g_t * s) + eps * n_t, s = (1, .5, .25, ...); B and g_t are drawn per
+    parameter.  Returns (task buffers, views[p][t]).
+
+    The whole batch is generated in O(n_tasks * rank) launches over the concatenated buffers (one ``normal_`` per
+    task buffer, one per column of B, one gather + one fused multiply-add per task and column) -- not one handful of
+    launches per (parameter, task): the ~14 000 tiny dispatches of the earlier per-tensor loop were the storm every
+    ``rocprofv3 --pmc`` crash of round 2 died in (profiles/README.md), and they cost seconds of start-up.  The
+    stream is synchronised before returning, so no generator work is in flight when the first svdq kernel starts."""
     dev = torch.device(device)
     offs, tot = [], 0
     for d in rows:
         offs.append(tot)
         tot += (d + 63) // 64 * 64
     g = torch.Generator(device=dev).manual_seed(seed)
-    bufs = [torch.empty(tot, dtype=torch.float32, device=dev) for _ in range(n_tasks)]
+    P = len(rows)
+    sizes = torch.tensor([(d + 63) // 64 * 64 for d in rows], dtype=torch.int64, device=dev)
+    pid = torch.repeat_interleave(torch.arange(P, dtype=torch.int32, device=dev), sizes, output_size=tot)
     s = torch.tensor([0.5 ** i for i in range(rank)], device=dev)
-    views: List[List[torch.Tensor]] = []
-    for d, o in zip(rows, offs):
-        B = torch.randn(d, rank, device=dev, generator=g)
-        vs = []
-        for t in range(n_tasks):
-            gt = torch.randn(rank, device=dev, generator=g)
-            v = bufs[t][o:o + d]
-            torch.randn(d, device=dev, generator=g, out=v)
-            v.mul_(eps).add_((B * (gt * s)).sum(dim=1), alpha=a)
-            vs.append(v)
-        views.append(vs)
-        del B
+    gts = torch.randn(n_tasks, rank, P, device=dev, generator=g) * (a * s).view(1, rank, 1)   # a * g_t * s per parameter
+    Bs = [torch.randn(tot, device=dev, generator=g) for _ in range(rank)]
+    bufs = []
+    for t in range(n_tasks):
+        b = torch.empty(tot, dtype=torch.float32, device=dev)
+        b.normal_(generator=g).mul_(eps)
+        for r in range(rank):
+            b.addcmul_(Bs[r], gts[t, r].index_select(0, pid))
+        bufs.append(b)
+    del Bs, pid, gts
+    views = [[bufs[t][o:o + d] for t in range(n_tasks)] for d, o in zip(rows, offs)]
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()      # the generator's temporaries go back to the driver: output placement is tuned later
     return bufs, views

@@ -588,6 +588,144 @@ def test_gather_mode_bit_identical(sq, orc, N, fp16, density):
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
+@pytest.mark.parametrize("N,fp16,density,unit_rows", [(8, True, 0.94, 1024), (8, True, 0.2, 1024), (5, False, 0.6, 0),
+                                                      (16, True, 0.9, 2048), (12, True, 0.5, 0), (3, True, 0.97, 256)])
+def test_walk_mode_bit_identical(sq, orc, N, fp16, density, unit_rows):
+    """svdq_compress_masked (source rows walked with the mask byte beside them, selected rows compacted in LDS; no
+    index lists, no compacted copies) produces exactly the artifacts of svdq_compress on the compacted tensors --
+    signal region and, with the inverted polarity, noise region alike; unit starts point at the right elements."""
+    from svdq_amd.pipeline import CompressPlan
+    from svdq_amd.mask_loader import MaskSet
+    dev = torch.device("cuda", 0)
+    sizes = [300000, 777, 70001, 1024 * 96, 5000, 262144 + 3, 12, 4096 * 3, 2049]
+    g = torch.Generator().manual_seed(19)
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 490 + i)] for i, D in enumerate(sizes)]
+    masks = [(torch.rand(D, generator=g) < density).to(dev) for D in sizes]
+    masks[4][:] = True                                   # fully selected,
+    masks[6][:] = False                                  # empty,
+    masks[7][:] = False
+    masks[7][::3] = True                                 # exactly 4096 selected rows: units end on block boundaries
+    masks[8][:] = False
+    masks[8][-1] = True                                  # a single row, the last element of the tensor
+    masks[0][:1000] = False                              # a long unselected prefix
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=fp16, low_bits=4, rtvq_stages=2, device=dev,
+              unit_rows=unit_rows)
+    ms = MaskSet(sizes, dev)
+    dt, df, ct, cf = ms.compact(masks, vecs, want_false=True)
+    ct2, cf2 = ms.count_scan(masks)
+    assert torch.equal(ct, ct2) and torch.equal(cf, cf2)
+    mtab = torch.tensor([m.data_ptr() for m in ms._s["mb"]], dtype=torch.int64).to(dev)
+    for compacted, cnt, inv in ((dt, ct, False), (df, cf, True)):
+        ref = CompressPlan(sizes, N, **kw)
+        ref.run(ref.pointer_table(compacted), cnt)
+        wlk = CompressPlan(sizes, N, **kw)
+        us = ms.unit_starts(wlk, cnt, entry_map=[(q, inv) for q in range(len(sizes))] if inv else None)
+        # the starts are the positions of the rows the units begin with
+        ush = us.cpu()
+        ubeg = np.cumsum([0] + [(D + (unit_rows or 4096) - 1) // (unit_rows or 4096) for D in sizes])
+        for q, D in enumerate(sizes):
+            sel = torch.nonzero(~masks[q] if inv else masks[q]).flatten().cpu()
+            if unit_rows:
+                for j in range(int(ubeg[q + 1] - ubeg[q])):
+                    got = int(ush[ubeg[q] + j]) & ((1 << 62) - 1)
+                    assert ((int(ush[ubeg[q] + j]) >> 62) & 1) == int(inv)
+                    want = int(sel[j * unit_rows]) if j * unit_rows < sel.numel() else D
+                    assert got == want, (q, j, got, want)
+        wlk.run_masked(wlk.pointer_table(vecs), mtab, us, cnt)
+        torch.cuda.synchronize()
+        sm, sg = ref.fetch_small(), wlk.fetch_small()
+        assert torch.equal(wlk.small, ref.small)
+        for p in range(len(sizes)):
+            rows = int(sm.rows[p])
+            assert rows == int(cnt[p])
+            a = ref.basis_tensors(p, int(sm.k[p]), int(sm.r[p]), rows)
+            b = wlk.basis_tensors(p, int(sg.k[p]), int(sg.r[p]), rows)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+def test_walk_mode_from_checkpoints_and_limits(sq, orc):
+    """svdq_compress_masked_from_base == svdq_ingest + svdq_compress_masked, bit for bit; N > 16 is refused (the
+    index lists serve it); a plan whose rows differ from the mask set is refused."""
+    from svdq_amd.pipeline import CompressPlan
+    from svdq_amd.mask_loader import MaskSet
+    dev = torch.device("cuda", 0)
+    N, sizes = 6, [100003, 513, 40960]
+    g = torch.Generator().manual_seed(5)
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 90 + i)] for i, D in enumerate(sizes)]
+    base = [torch.randn(D, generator=g).to(dev) for D in sizes]
+    ft = [[base[p] + vecs[p][t] for t in range(N)] for p in range(len(sizes))]
+    deltas = [[ft[p][t] - base[p] for t in range(N)] for p in range(len(sizes))]     # what the ingest would write
+    masks = [(torch.rand(D, generator=g) < 0.8).to(dev) for D in sizes]
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=True, low_bits=4, rtvq_stages=2, device=dev)
+    ms = MaskSet(sizes, dev)
+    ct, _ = ms.count_scan(masks)
+    mtab = torch.tensor([m.data_ptr() for m in ms._s["mb"]], dtype=torch.int64).to(dev)
+    a = CompressPlan(sizes, N, **kw)
+    us = ms.unit_starts(a, ct)
+    a.run_masked(a.pointer_table(deltas), mtab, us, ct)
+    b = CompressPlan(sizes, N, **kw)
+    btab = torch.tensor([x.data_ptr() for x in base], dtype=torch.int64).to(dev)
+    b.run_masked_from_base(b.pointer_table(ft), btab, mtab, ms.unit_starts(b, ct), ct)
+    torch.cuda.synchronize()
+    assert torch.equal(a.small, b.small) and torch.equal(a.basis, b.basis) and torch.equal(a.mean, b.mean)
+    big = CompressPlan(sizes, 20, **kw)
+    v20 = [[vecs[p][t % N] for t in range(20)] for p in range(len(sizes))]
+    with pytest.raises(RuntimeError, match="N <= 16"):
+        big.run_masked(big.pointer_table(v20), mtab, ms.unit_starts(big, ct), ct)
+    other = CompressPlan([s + 1 for s in sizes], N, **kw)
+    with pytest.raises(ValueError, match="Shape mismatch"):
+        ms.unit_starts(other, ct)
+
+
+@pytest.mark.parametrize("strategy", ["union", "majority"])
+def test_combine_starts_equals_combine_then_starts(sq, orc, strategy):
+    """The 3-launch combine + scan + unit-start entry (bool-byte and bit-packed per-task masks) against the separate
+    steps; the walk over its outputs against the index-list run on the same combined masks."""
+    from svdq_amd.pipeline import CompressPlan
+    from svdq_amd.mask_loader import MaskSet
+    dev = torch.device("cuda", 0)
+    N, sizes = 5, [300001, 777, 2048 * 5, 12]
+    g = torch.Generator().manual_seed(29)
+    per_task = [[(torch.rand(D, generator=g) > 0.6).to(dev) for _ in range(N)] for D in sizes]
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 700 + i)] for i, D in enumerate(sizes)]
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=True, low_bits=4, rtvq_stages=2, device=dev)
+    a = MaskSet(sizes, dev)
+    comb, counts = a.combine(per_task, strategy)
+    it, _, ct, _ = a.indices([c.view(torch.bool) for c in comb], want_false=False)
+    ref = CompressPlan(sizes, N, **kw)
+    ref.run_gather(ref.pointer_table(vecs), torch.tensor([x.data_ptr() for x in it], dtype=torch.int64).to(dev), ct)
+    b = MaskSet(sizes, dev)
+    wlk = CompressPlan(sizes, N, **kw)
+    outs, ct2, us = b.prepare_combine_starts(per_task, strategy, wlk)
+    b.run_combine_starts()
+    mtab = torch.tensor([o.data_ptr() for o in outs], dtype=torch.int64).to(dev)
+    wlk.run_masked(wlk.pointer_table(vecs), mtab, us, ct2)
+    torch.cuda.synchronize()
+    assert torch.equal(ct, ct2)
+    for q in range(len(sizes)):
+        assert torch.equal(comb[q], outs[q])
+    assert torch.equal(us, a.unit_starts(ref, ct))
+    assert torch.equal(ref.small, wlk.small) and torch.equal(ref.basis, wlk.basis) and torch.equal(ref.mean, wlk.mean)
+    # bit-packed input: one stream per task over the concatenated parameters
+    wts = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8, device=dev)
+    streams = []
+    for t in range(N):
+        bits = torch.cat([per_task[p][t] for p in range(len(sizes))])
+        pad = (-bits.numel()) % 8
+        if pad:
+            bits = torch.cat([bits, torch.zeros(pad, dtype=torch.bool, device=dev)])
+        streams.append((bits.view(-1, 8).to(torch.uint8) * wts).sum(dim=1, dtype=torch.uint8))
+    offs = [int(x) for x in np.cumsum([0] + sizes[:-1])]
+    c = MaskSet(sizes, dev)
+    pk = CompressPlan(sizes, N, **kw)
+    outs3, ct3, us3 = c.prepare_combine_packed_starts(streams, offs, strategy, pk)
+    c.run_combine_packed_starts()
+    torch.cuda.synchronize()
+    assert torch.equal(ct3, ct) and torch.equal(us3, us)
+    for q in range(len(sizes)):
+        assert torch.equal(outs3[q], outs[q])
+
+
 @pytest.mark.parametrize("strategy", ["union", "intersection", "majority"])
 def test_combine_indices_equals_combine_then_indices(sq, strategy):
     from svdq_amd.mask_loader import MaskSet
