@@ -1146,11 +1146,10 @@ UNROLL_N(SVDQ_UNROLL_BP)
                 const f32x4 mean = row_mean<NTP>(v0, NT, center);
 #pragma unroll
                 for (int t = 0; t < NTP; ++t) v0[t] = (t < NT) ? (v0[t] - mean) : zero4();
-                if (gmean) {   // mean of the compacted rows: consecutive lanes, consecutive rows
-                    const int64_t m0 = rb - fill0;      // compacted row of strip position 0
+                if (gmean) {   // mean of the compacted rows (strip position 0 = row rb): consecutive lanes, consecutive rows
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (w.sel[e] && m0 + w.pos[e] < D) gmean[m0 + w.pos[e]] = mean[e];
+                        if (w.sel[e] && rb + w.pos[e] < D) gmean[rb + w.pos[e]] = mean[e];
                 }
                 walk_scatter<NTP>(X, v0, w, 0);
             } else {
