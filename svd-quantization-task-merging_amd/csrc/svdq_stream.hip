@@ -1129,6 +1129,9 @@ UNROLL_N(SVDQ_UNROLL_BP)
         const int need = (r_begin < r_end) ? (int)(r_end - r_begin) : 0;
         int produced = 0, fill = 0;
         int64_t rb = r_begin;
+        // (A second register set taking the NEXT chunk's loads while this one is ingested and its block computed was
+        // measured: 0.850-0.868 ms against 0.860 ms for pass 2 of ViT-B-16 x 8 on the same box, with 11 spilled dwords
+        // to stay at three waves per SIMD -- the twelve waves of a CU already keep the loads flowing.  Not kept.)
         unsigned mk[4];
         bool have = need > 0 && src < src_end;
         if (have) walk_load<NTP, SUB>(v0, vb, mk, bp, gbase, gmask, src, src_end, lane);
