@@ -89,6 +89,13 @@ def parse():
                     help="A/B: XCD-chunked unit order in both passes (each XCD walks a contiguous eighth of the units)")
     ap.add_argument("--bp2", action="store_true",
                     help="A/B, N = 17..20: the two-wave pass 2 (round 1) instead of the one-wave 4x4-block kernel")
+    ap.add_argument("--merge", action="store_true",
+                    help="time the CONSUMER leg instead (BASELINE configs[4] 'cluster-weighted merge'; reference "
+                         "merge.py:304-626 + apply_merged_deltas): artifacts resident in HBM -> merged model (base + "
+                         "merged delta, fp32) resident in HBM; a step = svdq_merge over the whole plan (coefficient "
+                         "averaging from the small-artifact buffer + one streaming reconstruction).  --clusters K "
+                         "merges K clusters of tasks and combines them with softmax shares in the same pass")
+    ap.add_argument("--clusters", type=int, default=1, help="--merge: number of task clusters (sets), 1..8")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -257,6 +264,30 @@ def cpu_baseline(names, rows, n_tasks, args, threads=None, seconds=None):
             "sample": f"{args.model} x {n_tasks} tasks: tensors of [{', '.join(sample_desc[:2])}"
                       f"{' ...' if len(sample_desc) > 2 else ''}] = {len(sample_desc) - 1} resblocks + globals, "
                       f"{scalars / 1e6:.1f} M scalars in {spent:.1f} s (oracle: torch-CPU stack/mean/gesdd/project + C quantizer)"}
+
+
+def cpu_merge_baseline(names, rows, n_tasks, args):
+    """--merge: the oracle's restatement of the reference merge (per parameter: dequantize every task's payloads,
+    weighted average, U c + mean, base + delta; merge.py:61-194, 429-552) on a bounded sample of the same tensors."""
+    from oracle import svd_hybrid_oracle as orc
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    scalars, spent, done = 0, 0.0, 0
+    for i in sorted(range(len(rows)), key=lambda j: -rows[j]):
+        deltas = orc.synthetic_deltas(rows[i], n_tasks, 1000 + i)
+        ref = orc.compress_parameter(deltas, args.energy, 64, True, True, args.bits, args.stages)
+        base = torch.randn(rows[i])
+        t1 = time.perf_counter()
+        orc.merge_parameter(ref, [1.0 / n_tasks] * n_tasks, base)
+        spent += time.perf_counter() - t1
+        scalars += rows[i] * n_tasks
+        done += 1
+        if spent >= args.cpu_seconds / 3:
+            break
+    return {"value": round(scalars / spent / 1e6, 2), "unit": "MParams/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model(),
+            "sample": f"the {done} largest tensors of {args.model} x {n_tasks} tasks, {scalars / 1e6:.1f} M scalars in "
+                      f"{spent:.2f} s (oracle: per task dequantize, weighted average, U c + mean, base + delta on torch-CPU)"}
 
 
 # ------------------------------------------------------------------------------------------------ one workload
@@ -437,6 +468,75 @@ class Workload:
         return elapsed, scalars, kms
 
 
+def merge_leg(wl, args, dev):
+    """--merge: K timed steps of the plan-level merge (two launches per step) after one compression; returns the JSON
+    fields.  Weights: uniform inside each cluster; clusters = contiguous groups of tasks; shares = softmax of the
+    clusters' mean weights (all equal here), renormalised on the device as apply_weights_to_tensors does."""
+    import numpy as np
+    from ctypes import c_void_p
+    from svdq_amd.pipeline import _ptr, _stream_ptr
+    plan, N, S = wl.plan, args.tasks, max(1, min(args.clusters, 8, args.tasks))
+    lib = wl.lib
+    plan.run(wl.table)
+    torch.cuda.synchronize()
+    wt = np.full((S, N), -1.0, dtype=np.float32)
+    for t in range(N):
+        c = t * S // N
+        members = [u for u in range(N) if u * S // N == c]
+        wt[c, t] = np.float32(1.0 / len(members))
+    wt_d = torch.from_numpy(wt).to(dev)
+    sh_d = None
+    if S > 1:
+        sh = torch.softmax(torch.full((S,), 1.0 / N), dim=0).to(dev)
+        sh_d = (sh / sh.sum()).contiguous()
+    base = [torch.randn(r, device=dev) for r in wl.rows]
+    btab = torch.tensor([b.data_ptr() for b in base], dtype=torch.int64).to(dev)
+    buf, offs, otab = plan.merged_outputs()
+    work = torch.empty(int(lib.svdq_merge_work_bytes(plan._h, S)), dtype=torch.uint8, device=dev)
+    steps, warm = args.steps, args.warmup
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        lib.svdq_merge_coeffs(plan._h, _ptr(plan.small), _ptr(wt_d), c_void_p(0), S, 0, _ptr(work), _stream_ptr())
+        if ev is not None:
+            ev[1].record()
+        rc = lib.svdq_merge_reconstruct(plan._h, c_void_p(0), _ptr(plan.small), _ptr(plan.basis), _ptr(plan.mean),
+                                        _ptr(work), S, 0, _ptr(sh_d), c_void_p(0), _ptr(btab), _ptr(otab), _stream_ptr())
+        if ev is not None:
+            ev[2].record()
+        assert rc == 0, rc
+    for _ in range(warm):
+        step()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        step(ev[s_])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kms = [sum(ev[s_][i].elapsed_time(ev[s_][i + 1]) for s_ in range(steps)) / steps for i in range(2)]
+    sumD = float(sum(wl.rows))
+    # algorithmic bytes of the streaming launch: U fp16 (2 N) + mean + base read, fp32 out written
+    rec_bytes = sumD * (2 * N + 12)
+    gbs = rec_bytes / (kms[1] * 1e-3) / 1e9
+    ms = elapsed / steps * 1e3
+    return {
+        "metric": "MParams/s merged (coefficients in HBM -> base + merged delta in HBM; Params = N_tasks * sum D_p)",
+        "value": round(sumD * N / (elapsed / steps) / 1e6, 1), "unit": "MParams/s", "n_gpus": 1, "steps": steps,
+        "warmup": warm, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "none", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} visual encoder x {N} tasks: merge of the compressed artifacts, "
+                               f"{S} cluster(s), + base (apply_merged_deltas fused), {len(wl.rows)} tensors, "
+                               f"sum D = {int(sumD)}", "tasks": N, "clusters": S,
+                   "schedule": "2 kernels: merge_coeff, merge_reconstruct"},
+        "roofline": {"bound": "hbm", "kernel": "k_merge_reconstruct", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes": int(rec_bytes), "avg_ms": round(kms[1], 4)},
+        "kernels_ms": {"k_merge_coeff": round(kms[0], 4), "k_merge_reconstruct": round(kms[1], 4)},
+    }
+
+
 def basis_gather_ms(plan, dist, dev, on_cpu):
     """Cost of ALSO collecting the fp16 bases: one padded all_gather_into_tensor of every rank's packed
     basis buffer, timed on its own (never part of `value`)."""
@@ -502,6 +602,14 @@ def main():
                 f.write(open("/proc/self/maps").read())
         except OSError:
             pass
+    if args.merge:
+        if world > 1 or args.masks != "none" or args.from_base != "off":
+            sys.exit("bench.py --merge: one GPU, unmasked task vectors")
+        out = merge_leg(wl, args, dev)
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_merge_baseline(names, rows, N, args)
+        print(json.dumps(out), flush=True)
+        return
     # after the inputs exist: the probe walks through device memory and leaves holes in several regions behind, which
     # later allocations would be scattered over
     try:

@@ -389,6 +389,45 @@ int svdq_recon_error(const void *u_high_dev, const void *u_low_dev, int32_t u_fp
                      int32_t nl, const float *coef_dev, const float *mean_dev, const float *recon_dev,
                      const float *orig_dev, double *out6_dev, void *work_dev, void *stream);
 
+/* ---- the same consumers for a WHOLE PLAN, straight from the buffers the compressor left in HBM (no host copy of the
+ *      payloads, no per-parameter / per-task launch): what cli.py Steps 7-9 do parameter by parameter --
+ *      merge_all_parameters (merge.py:304-426) -> merge_parameter (:197-301) -> dequantize_and_average (:61-141, with
+ *      RTVQQuantizer.dequantize rtvq.py:85-103) + reconstruct_from_coefficients (:144-194); merge_with_clustering
+ *      (:555-626) + merge_cluster_results (clustering.py:374-425); apply_merged_deltas (merge.py:429-552);
+ *      compute_parameter_diagnostics (diagnostics.py:120-231).
+ *   A "set" is a group of tasks averaged together: one set of all tasks (merge_all_parameters), one per cluster
+ *   (merge_with_clustering) or one per task (diagnostics).
+ *   weights_dev: float [n_sets][N] (per_param = 0) or [P][n_sets][N] (per_param = 1): weight of task t in set s,
+ *     renormalised over the set's present tasks as the reference does on the host (merge.py:123-124); < 0 = not in the set.
+ *   order_dev:   NULL or int32 [N] / [P][N]: task indices in the order of the sorted task names (merge.py:89).
+ *   svdq_merge_coeffs: cbar_dev float [P][n_sets][N] = averaged c_high (columns < k) and dequantized c_low (k..r-1).
+ *   svdq_merge_reconstruct: one streaming launch over the plan's units,
+ *       out[p][d] = sum_s share[s] * (((U_high c_s,high + U_low c_s,low)[d] + mean[d]) * scale[p])  (+ base[p][d])
+ *     set_share_dev: NULL (n_sets = 1: no weighting) or float [n_sets] / [P][n_sets], the clusters' shares renormalised
+ *     as apply_weights_to_tensors does (weighting.py:332-372), < 0 = set absent; n_sets <= 8.
+ *     scale_dev: NULL or float [P] (noise_shrink of the noise regions, merge.py:270); base_ptrs_dev: NULL or [P] base
+ *     tensors (then out = base + delta); out_ptrs_dev [P] fp32 outputs of rows[p] elements (compacted rows for masked
+ *     parameters: svdq_mask_expand scatters them).  A parameter's rows are the bits svdq_reconstruct gives.
+ *   svdq_merge = both; work_dev: svdq_merge_work_bytes(plan, n_sets).
+ *   svdq_diagnostics: out_dev double [P][N][6], the six numbers of svdq_recon_error for every (parameter, task) from
+ *     one pass over U and the N deltas (delta_ptrs_dev as for svdq_compress); add_mean = 0 reproduces the reference
+ *     (SURVEY Q1).  work_dev: svdq_diagnostics_work_bytes(plan). */
+int64_t svdq_merge_work_bytes(const svdq_plan *plan, int32_t n_sets);
+int svdq_merge_coeffs(const svdq_plan *plan, const void *small_dev, const float *weights_dev, const int32_t *order_dev,
+                      int32_t n_sets, int32_t per_param, float *cbar_dev, void *stream);
+int svdq_merge_reconstruct(const svdq_plan *plan, const int64_t *rows_dev, const void *small_dev, const void *basis_dev,
+                           const float *mean_dev, const float *cbar_dev, int32_t n_sets, int32_t per_param,
+                           const float *set_share_dev, const float *scale_dev, const void *base_ptrs_dev,
+                           const void *out_ptrs_dev, void *stream);
+int svdq_merge(const svdq_plan *plan, const int64_t *rows_dev, const void *small_dev, const void *basis_dev,
+               const float *mean_dev, const float *weights_dev, const int32_t *order_dev, int32_t n_sets,
+               int32_t per_param, const float *set_share_dev, const float *scale_dev, const void *base_ptrs_dev,
+               const void *out_ptrs_dev, void *work_dev, void *stream);
+int64_t svdq_diagnostics_work_bytes(const svdq_plan *plan);
+int svdq_diagnostics(const svdq_plan *plan, const void *delta_ptrs_dev, const int64_t *rows_dev, const void *small_dev,
+                     const void *basis_dev, const float *mean_dev, int32_t add_mean, double *out_dev, void *work_dev,
+                     void *stream);
+
 /* ---- measurement aid (no reference counterpart; SURVEY.md section 8d asks for "a measured device-copy ceiling on
  *      the box" beside the 8 TB/s specification): plain streaming kernels with the access shape of the two passes.
  *      mode 0: read `bytes` from src_dev (dst_dev receives one float per 256 KiB read); mode 1: copy `bytes`;

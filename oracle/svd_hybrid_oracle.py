@@ -346,6 +346,20 @@ def compress_parameter(deltas: Sequence[torch.Tensor], energy_threshold: float =
     return {"basis": basis, "tasks": tasks, "recon": recon, "vectors": vecs}
 
 
+def merge_parameter(comp: Dict, weights: Sequence[float], base: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """merge.py:61-141 + 144-194 (+ 429-552 with ``base``) for one parameter from compress_parameter's output:
+    per task fp16 c_high -> fp32 and dequantized c_low, weights renormalised over the tasks, weighted average,
+    U_high c_high + U_low c_low + mean, base + delta."""
+    basis = comp["basis"]
+    tot = float(sum(weights))
+    w = torch.tensor([float(x) / tot for x in weights], dtype=torch.float32).view(-1, 1)
+    highs = torch.stack([t["c_high_fp16"].float() for t in comp["tasks"]], dim=0)
+    lows = torch.stack([torch.from_numpy(rtvq_dequantize(t["c_low_quant"]).reshape(-1).copy()) for t in comp["tasks"]],
+                       dim=0)
+    delta = reconstruct((highs * w).sum(dim=0), (lows * w).sum(dim=0), basis["U_high"], basis["U_low"], basis["mean"])
+    return delta if base is None else base + delta
+
+
 # --------------------------------------------------------------------------- synthetic inputs
 def synthetic_deltas(D: int, N: int, seed: int, rank: int = 3, a: float = 0.01, eps: float = 0.002,
                      device: str = "cpu") -> List[torch.Tensor]:

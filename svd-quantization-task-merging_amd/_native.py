@@ -111,6 +111,15 @@ SIGNATURES = {
     "svdq_recon_error_work_bytes": (c_int64, [c_int64]),
     "svdq_recon_error": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_merge_work_bytes": (c_int64, [c_void_p, c_int32]),
+    "svdq_merge_coeffs": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "svdq_merge_reconstruct": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_merge": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "svdq_diagnostics_work_bytes": (c_int64, [c_void_p]),
+    "svdq_diagnostics": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                   c_void_p, c_void_p]),
     "svdq_mask_expand": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "svdq_hbm_probe": (c_int32, [c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
 }

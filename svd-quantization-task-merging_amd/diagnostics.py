@@ -113,6 +113,66 @@ def compute_parameter_diagnostics(param_name: str, task_vectors: Dict[str, Dict[
     return diag
 
 
+def _batched_errors(task_vectors, compressed_all, bases, masks) -> Dict[str, Dict]:
+    """compute_parameter_diagnostics for every unmasked parameter whose artifacts still live in the buffers of a fused
+    run: ONE pass over U and the N deltas per plan (svdq_diagnostics: all N error tuples of a parameter from a single
+    read of its basis) and one small D2H copy, instead of a payload upload + dequantize + fused-error launch per
+    (parameter, task).  Same dictionaries; parameters it cannot take (masked, foreign artifacts, other tensors than
+    the run compressed) are left to the per-parameter route."""
+    from .merge import _batched_entry
+    plans = {}
+    for name in bases.keys():
+        if name not in compressed_all or masks.get(name) is not None:
+            continue
+        got = _batched_entry(name, compressed_all, bases)
+        if got is None:
+            continue
+        batch, i, meta = got
+        if getattr(batch, "mode", None) != "plain" or getattr(batch, "from_base", True):
+            continue
+        # the error is measured against the tensors the CALLER passes: they must be the ones the plan still points at
+        kept = batch.plan._keep[i] if batch.plan._keep is not None else None
+        tasks_i = batch.task_names[i]
+        if kept is None or any(t not in task_vectors or name not in task_vectors[t] or
+                               task_vectors[t][name].data_ptr() != kept[j].data_ptr() or
+                               task_vectors[t][name].numel() != kept[j].numel() for j, t in enumerate(tasks_i)):
+            continue
+        plans.setdefault(id(batch), (batch, []))[1].append((name, i, meta))
+    out = {}
+    for batch, items in plans.values():
+        plan, small = batch.plan, batch.small
+        with torch.cuda.device(plan.device):
+            res = plan.diagnostics(batch.table, batch.rows_dev).cpu().numpy()      # [P, N, 6]
+        for name, i, meta in items:
+            tasks_i = batch.task_names[i]
+            pos = {t: j for j, t in enumerate(tasks_i)}
+            first = next(iter(task_vectors.keys()))
+            diag = {"param_name": name, "original_shape": None, "masked_size": 0, "unmasked_size": 0,
+                    "reconstruction_errors": {}, "compression_ratios": {}}
+            if name in task_vectors[first]:
+                diag["original_shape"] = list(task_vectors[first][name].shape)
+            diag["masked_size"] = np.prod(diag["original_shape"])
+            k, r, rows = int(small.k[i]), int(small.r[i]), int(small.rows[i])
+            diag["basis"] = {"k": k, "D": rows, "N": plan.N, "energy_retained": float(small.energy[i])}
+            nl, bits, stages = r - k, plan.bits_of(i), plan.S
+            ratio = (nl * 4) / max(nl * bits / 8 * stages + 8 * stages, 1)      # estimate_compression_ratio, rtvq.py:142-161
+            errs = []
+            for task in task_vectors.keys():
+                if name not in task_vectors[task] or task not in pos or task not in meta["have"]:
+                    continue
+                m = {key: float(v) for key, v in zip(_KEYS, res[i, pos[task]])}
+                errs.append(m["relative_error"])
+                diag["reconstruction_errors"][task] = m
+                diag["compression_ratios"][task] = ratio
+            if errs:
+                diag["mean_relative_error"] = float(np.mean(errs))
+                diag["std_relative_error"] = float(np.std(errs))
+                diag["max_relative_error"] = float(np.max(errs))
+                diag["min_relative_error"] = float(np.min(errs))
+            out[name] = diag
+    return out
+
+
 def compute_all_diagnostics(task_vectors: Dict[str, Dict[str, torch.Tensor]], compressed_all: Dict[str, Dict],
                             bases: Dict[str, Dict], masks: Dict[str, torch.Tensor], config, device: str = "cpu") -> Dict:
     """Reference diagnostics.py:234-321."""
@@ -121,8 +181,12 @@ def compute_all_diagnostics(task_vectors: Dict[str, Dict[str, torch.Tensor]], co
                       "svd_low_bits": config.svd_low_bits, "svd_rtvq_stages": config.svd_rtvq_stages,
                       "svd_mask_strategy": config.svd_mask_strategy, "svd_weighting": config.svd_weighting},
            "per_parameter": {}, "summary": {}}
+    pre = _batched_errors(task_vectors, compressed_all, bases, masks)
     for name in sorted(bases.keys()):
         if name not in compressed_all:
+            continue
+        if name in pre:
+            out["per_parameter"][name] = pre[name]
             continue
         out["per_parameter"][name] = compute_parameter_diagnostics(name, task_vectors, compressed_all[name],
                                                                    bases[name], masks.get(name), quantizer, device)

@@ -164,6 +164,9 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
             batch = BatchResult(plan, small, [(e["name"], e["region"]) for e in entries],
                                 [e["tasks"] for e in entries])
             batch.keep = keep
+            # for the batched consumers (svdq_diagnostics reads the deltas again): what the run was launched with
+            batch.mode, batch.table, batch.rows_dev = mode, table, rows_dev
+            batch.from_base = base_state is not None
             for i, e in enumerate(entries):
                 slot = bases.setdefault(e["name"], {"masked": None, "noise": None})
                 if int(small.rows[i]) <= 0:
@@ -183,12 +186,13 @@ class LazyArtifacts(dict):
     dictionaries per model.  storage.save_compressed_coefficients writes plain dicts (as the reference's writer
     does: it rebuilds the per-task level); pickled / torch.saved directly it comes back as a collections.OrderedDict,
     the one mapping type the weights-only unpickler admits besides dict itself."""
-    __slots__ = ("_fill", "_batch")
+    __slots__ = ("_fill", "_batch", "_meta")
 
-    def __init__(self, fill, batch=None):
+    def __init__(self, fill, batch=None, meta=None):
         super().__init__()
         self._fill = fill
         self._batch = batch      # (BatchResult, index): where this parameter's results live
+        self._meta = meta        # compressed_all entries: which tasks / noise entry, for the batched consumers
 
     def _ensure(self):
         f = self._fill
@@ -251,7 +255,9 @@ def artifacts_from_batch(name: str, basis: Dict, task_vectors, config) -> Option
             out[t] = art
         return out
 
-    return LazyArtifacts(fill)
+    return LazyArtifacts(fill, batch=bm._batch,
+                         meta={"have": have, "tasks": tasks_i,
+                               "noise": bn._batch if (bn is not None and getattr(bn, "_batch", None) is not None) else None})
 
 
 def run_basis_and_compress(task_vectors, combined_masks, config, device="cuda") -> Tuple[Dict, Dict]:

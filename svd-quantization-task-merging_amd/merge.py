@@ -33,8 +33,14 @@ def dequantize_and_average(compressed_coeffs: Dict[str, Dict], weights: Dict[str
     if not highs:
         return None, None
     tot = sum(ws)
-    w = torch.tensor([x / tot for x in ws], device=device, dtype=torch.float32).view(-1, 1)
-    return (torch.stack(highs, dim=0) * w).sum(dim=0), (torch.stack(lows, dim=0) * w).sum(dim=0)
+    w = torch.tensor([x / tot for x in ws], device=device, dtype=torch.float32)
+    # (stack * w).sum(0) task by task: rounded products added in task order -- the association the batched kernel
+    # (k_merge_coeff) uses, so both routes give the same bits (torch's own reduction order depends on its launch shape)
+    hi, lo = highs[0] * w[0], lows[0] * w[0]
+    for j in range(1, len(highs)):
+        hi = hi + highs[j] * w[j]
+        lo = lo + lows[j] * w[j]
+    return hi, lo
 
 
 def reconstruct_from_coefficients(avg_c_high: torch.Tensor, avg_c_low: torch.Tensor, U_high: torch.Tensor,
@@ -111,14 +117,119 @@ def merge_parameter(param_name: str, compressed_params: Dict[str, Dict], basis: 
     return res.cpu() if wants_cpu(device) else res      # the reference returns on `device` (default "cpu")
 
 
+def _batched_entry(name, compressed_all, bases):
+    """(plan batch, index, meta) when both dictionaries of ``name`` still are what the fused run handed out."""
+    from .driver import LazyArtifacts
+    b, ca = bases.get(name), compressed_all.get(name)
+    bm = b.get("masked") if isinstance(b, dict) else None
+    if (isinstance(bm, LazyArtifacts) and bm._batch is not None and isinstance(ca, LazyArtifacts)
+            and ca._meta is not None and ca._batch is not None and ca._batch[0] is bm._batch[0]
+            and ca._batch[1] == bm._batch[1]):
+        return bm._batch[0], bm._batch[1], ca._meta
+    return None
+
+
+def _task_weights(have, tasks_i, members, weights):
+    """One row of the weight table of k_merge_coeff: the reference's renormalised weights (merge.py:89-124) of the
+    tasks of ``members`` (None = all) that have the parameter, in the plan's task order; -1 = not in the set."""
+    import numpy as np
+    names = sorted(t for t in have if members is None or t in members)
+    present = [t for t in names if t in tasks_i]
+    row = np.full(len(tasks_i), -1.0, dtype=np.float32)
+    if not present:
+        return row, False
+    ws = [weights.get(t, 1.0 / len(names)) for t in present]
+    tot = sum(ws)
+    pos = {t: j for j, t in enumerate(tasks_i)}
+    for t, x in zip(present, ws):
+        row[pos[t]] = np.float32(x / tot)
+    return row, True
+
+
+def _merge_batched(names, compressed_all, bases, masks, sets, original_shapes, config, device):
+    """merge_all_parameters / merge_with_clustering for the parameters whose artifacts still live in the buffers of a
+    fused run: per plan ONE coefficient kernel + ONE streaming reconstruction (svdq_merge) instead of, per parameter
+    and task, a host->device copy of the payloads, a dequantize launch, a stack/sum and a reconstruct launch.
+    ``sets``: [(weights dict, members or None)] and, for more than one set, their shares (device tensor).
+    Returns {name: merged delta} for the names it could take; the rest goes the per-parameter way."""
+    import numpy as np
+    from .mask_loader import reconstruct_from_masked
+    set_list, shares = sets
+    S = len(set_list)
+    if S > 8:
+        return {}
+    dev = resolve_device(device)
+    jobs = {}      # id(plan) -> (plan, {entry index: (name, region, meta)})
+    for name in names:
+        got = _batched_entry(name, compressed_all, bases)
+        if got is None:
+            continue
+        batch, i, meta = got
+        jobs.setdefault(id(batch.plan), (batch, {}))[1][i] = (name, "masked", meta)
+        if config.svd_include_noise and meta["noise"] is not None:
+            nb, j = meta["noise"]
+            jobs.setdefault(id(nb.plan), (nb, {}))[1][j] = (name, "noise", meta)
+    pieces = {}    # name -> {"masked": tensor, "noise": tensor}
+    with torch.cuda.device(dev):
+        for batch, entries in jobs.values():
+            plan, small = batch.plan, batch.small
+            P, N = plan.P, plan.N
+            wt = np.full((P, S, N), -1.0, dtype=np.float32)
+            order = np.tile(np.arange(N, dtype=np.int32), (P, 1))
+            scale = np.ones(P, dtype=np.float32)
+            share_ok = np.zeros((P, S), dtype=bool)
+            for i, (name, region, meta) in entries.items():
+                tasks_i = batch.task_names[i]
+                order[i] = np.argsort(np.array(tasks_i, dtype=object), kind="stable").astype(np.int32)
+                for s_, (w, members) in enumerate(set_list):
+                    wt[i, s_], share_ok[i, s_] = _task_weights(meta["have"], tasks_i, members, w)
+                if region == "noise":
+                    scale[i] = np.float32(config.svd_noise_shrink)
+            wt_d = torch.from_numpy(wt).to(plan.device)
+            ord_d = torch.from_numpy(order).to(plan.device)
+            sc_d = torch.from_numpy(scale).to(plan.device)
+            sh_d = None
+            if S > 1:
+                # apply_weights_to_tensors (weighting.py:332-372): shares renormalised over the sets a parameter has
+                ok = torch.from_numpy(share_ok).to(plan.device)
+                sh = torch.where(ok, shares.to(plan.device).view(1, S).expand(P, S), torch.zeros((), device=plan.device))
+                tot = torch.zeros(P, dtype=torch.float32, device=plan.device)
+                for s_ in range(S):      # w.sum() of <= 8 values, in set order
+                    tot = tot + sh[:, s_]
+                sh_d = torch.where(ok, sh / tot.view(P, 1), torch.full((), -1.0, device=plan.device)).contiguous()
+            rows_dev = plan.small[plan.layout.rows_off:plan.layout.rows_off + 8 * P].view(torch.int64)
+            buf, offs = plan.merge(wt_d, order=ord_d, set_share=sh_d, scale=sc_d, rows_dev=rows_dev)
+            for i, (name, region, meta) in entries.items():
+                rows = int(small.rows[i])
+                if rows > 0 and share_ok[i].any():
+                    pieces.setdefault(name, {})[region] = buf[offs[i]:offs[i] + rows]
+    out = {}
+    for name, pc in pieces.items():
+        if "masked" not in pc:
+            continue
+        mask = masks.get(name)
+        if mask is not None:
+            res = reconstruct_from_masked(pc["masked"], pc.get("noise"), mask, original_shapes[name])
+        else:
+            res = pc["masked"].view(original_shapes[name])
+        out[name] = res
+    return out
+
+
 def merge_all_parameters(compressed_all: Dict[str, Dict[str, Dict]], bases: Dict[str, Dict],
                          masks: Dict[str, torch.Tensor], weights: Dict[str, float],
                          original_shapes: Dict[str, torch.Size], config, device: str = "cpu",
                          verbose: bool = True) -> Dict[str, torch.Tensor]:
     """Reference merge.py:304-426: parameters in sorted order, one quantizer for the run."""
     quantizer = RTVQQuantizer(num_bits=config.svd_low_bits, num_stages=config.svd_rtvq_stages)
+    names = sorted(compressed_all.keys())
+    # parameters whose artifacts still live in a fused run's buffers: two launches per plan (svdq_merge)
+    fast = _merge_batched(names, compressed_all, bases, masks, ([(weights, None)], None), original_shapes, config, device)
     merged = {}
-    for name in sorted(compressed_all.keys()):
+    for name in names:
+        if name in fast:
+            merged[name] = fast[name].cpu() if wants_cpu(device) else fast[name]
+            continue
         merged[name] = merge_parameter(name, compressed_all[name], bases[name], weights, quantizer,
                                        original_shapes[name], mask=masks.get(name),
                                        include_noise=config.svd_include_noise, noise_shrink=config.svd_noise_shrink,
@@ -142,6 +253,33 @@ def apply_merged_deltas(base_state_dict: Dict[str, torch.Tensor], merged_deltas:
     return out
 
 
+def _merge_with_clustering_batched(compressed_all, bases, masks, weights, clusters, original_shapes, config, device):
+    """merge_with_clustering when EVERY parameter can take the batched route: the per-cluster merges and the share-weighted
+    sum over clusters happen inside one streaming pass per plan (the merge is linear in the coefficients).  None
+    otherwise (then the per-cluster loop below runs)."""
+    names = sorted(compressed_all.keys())
+    if not names or len(clusters) > 8 or any(_batched_entry(n, compressed_all, bases) is None for n in names):
+        return None
+    cids = sorted(clusters.keys())      # apply_weights_to_tensors adds the clusters in sorted-key order
+    sets, perf = [], []
+    for cid in cids:
+        members = clusters[cid]
+        w = {m: weights.get(m, 1.0) for m in members}
+        total = sum(w.values())
+        sets.append(({m: v / total for m, v in w.items()}, set(members)))
+        perf.append(sum(weights.get(m, 1.0) for m in members) / len(members))
+    # clustering.merge_cluster_results: softmax over the clusters in their first-seen order, looked up per cluster id
+    seen = list(clusters.keys())
+    sm = torch.softmax(torch.tensor([perf[cids.index(c)] for c in seen]), dim=0)
+    by_cid = {c: sm[j].item() for j, c in enumerate(seen)}
+    dev = resolve_device(device)
+    shares = torch.tensor([by_cid[c] for c in cids], device=dev, dtype=torch.float32)
+    fast = _merge_batched(names, compressed_all, bases, masks, (sets, shares), original_shapes, config, device)
+    if len(fast) != len(names):
+        return None
+    return {n: (t.cpu() if wants_cpu(device) else t) for n, t in fast.items()}
+
+
 def merge_with_clustering(compressed_all: Dict[str, Dict[str, Dict]], bases: Dict[str, Dict],
                           masks: Dict[str, torch.Tensor], weights: Dict[str, float],
                           cluster_assignments: Dict[str, int], original_shapes: Dict[str, torch.Size], config,
@@ -150,6 +288,9 @@ def merge_with_clustering(compressed_all: Dict[str, Dict[str, Dict]], bases: Dic
     average the cluster results with softmax(mean member weight) shares (clustering.py:374-425)."""
     from .clustering import get_cluster_members, merge_cluster_results
     clusters = get_cluster_members(cluster_assignments)
+    fast = _merge_with_clustering_batched(compressed_all, bases, masks, weights, clusters, original_shapes, config, device)
+    if fast is not None:
+        return fast
     per_cluster, performance = {}, {}
     for cid, members in clusters.items():
         w = {m: weights.get(m, 1.0) for m in members}

@@ -276,6 +276,56 @@ class CompressPlan:
                                                           _ptr(self.small), _ptr(self.basis), _ptr(self.mean),
                                                           _stream_ptr()), "svdq_compress_gather_from_base")
 
+    # ---- consumers of the artifacts, batched over the plan (svdq_merge.hip)
+    def merged_outputs(self):
+        """One packed fp32 buffer for the merged rows of every parameter (64-float aligned slices) + its device
+        pointer table; allocated on first use and reused by later merges of this plan."""
+        mo = getattr(self, "_merged", None)
+        if mo is None:
+            offs, tot = [], 0
+            for r in self.rows:
+                offs.append(tot)
+                tot += (r + 63) // 64 * 64
+            buf = torch.empty(tot, dtype=torch.float32, device=self.device)
+            base = buf.data_ptr()
+            table = torch.tensor([base + 4 * o for o in offs], dtype=torch.int64).to(self.device)
+            mo = self._merged = (buf, offs, table)
+        return mo
+
+    def merge(self, weights: torch.Tensor, order: Optional[torch.Tensor] = None, set_share: Optional[torch.Tensor] = None,
+              scale: Optional[torch.Tensor] = None, base_table: Optional[torch.Tensor] = None,
+              rows_dev: Optional[torch.Tensor] = None, out_table: Optional[torch.Tensor] = None):
+        """Coefficient averaging + reconstruction of every parameter of the plan in two launches (svdq_merge), from the
+        small-artifact and basis buffers of the last run.  ``weights``: float32 device tensor [S, N] (one table for
+        all parameters) or [P, S, N]; S sets (1 = merge_all_parameters, clusters = merge_with_clustering); entries
+        < 0 mark absent tasks.  ``order``: int32 [N] / [P, N] summation order (sorted task names).  ``set_share``:
+        float32 [S] / [P, S] (required when S > 1).  ``scale``: float32 [P] (noise_shrink).  ``base_table``: int64 [P]
+        base tensors -> out = base + delta.  Returns (packed output buffer, offsets) unless ``out_table`` is given."""
+        per_param = 1 if weights.dim() == 3 else 0
+        n_sets = int(weights.shape[-2])
+        own = out_table is None
+        if own:
+            buf, offs, out_table = self.merged_outputs()
+        work = getattr(self, "_merge_work", None)
+        need = int(self.lib.svdq_merge_work_bytes(self._h, n_sets))
+        if work is None or work.numel() < need:
+            work = self._merge_work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        nat.check(self.lib.svdq_merge(self._h, _ptr(rows_dev), _ptr(self.small), _ptr(self.basis), _ptr(self.mean),
+                                      _ptr(weights), _ptr(order), n_sets, per_param, _ptr(set_share), _ptr(scale),
+                                      _ptr(base_table), _ptr(out_table), _ptr(work), _stream_ptr()), "svdq_merge")
+        return (buf, offs) if own else None
+
+    def diagnostics(self, table, rows_dev: Optional[torch.Tensor] = None, add_mean: bool = False) -> torch.Tensor:
+        """[P, N, 6] float64 (device): absolute_error, relative_error, max_absolute_error, mean_absolute_error,
+        original_norm, reconstructed_norm of every (parameter, task) from one pass over U and the N deltas
+        (svdq_diagnostics; ``add_mean=False`` is the reference's Q1 behaviour)."""
+        out = torch.empty((self.P, self.N, 6), dtype=torch.float64, device=self.device)
+        work = torch.empty(int(self.lib.svdq_diagnostics_work_bytes(self._h)), dtype=torch.uint8, device=self.device)
+        nat.check(self.lib.svdq_diagnostics(self._h, _ptr(table), _ptr(rows_dev), _ptr(self.small), _ptr(self.basis),
+                                            _ptr(self.mean), int(bool(add_mean)), _ptr(out), _ptr(work), _stream_ptr()),
+                  "svdq_diagnostics")
+        return out
+
     def tune_placement(self, table, rows_dev=None, candidates: int = 6, reps: int = 2,
                        max_spacer_bytes: int = 32 << 30) -> List[float]:
         """Put the output buffers where pass 2 runs fastest.

@@ -284,3 +284,85 @@ def test_merge_with_clustering_vs_reference_vectors(sq):
         assert float(np.mean((m - gc[f"mwc__{p}"]) ** 2)) <= 1e-6
         ref = gc[f"mwc__{p}"]
         assert np.linalg.norm(m - ref) <= 0.25 * np.linalg.norm(ref), p   # same merge, independent 4-bit noise
+
+
+# ---------------------------------------------------------------------------- batched consumers (svdq_merge.hip)
+def _model_like(orc, tasks, with_masks):
+    """A small model: matrices, vectors, ragged sizes; optionally two masked parameters (dense and sparse masks)."""
+    shapes = {"blk.0.w": (96, 70), "blk.0.b": (96,), "blk.1.w": (300, 257), "emb": (1, 5000), "ln": (13,),
+              "blk.1.b": (4097,)}
+    tv = {t: {} for t in tasks}
+    for pi, (n, shp) in enumerate(sorted(shapes.items())):
+        for t, d in zip(tasks, orc.synthetic_deltas(int(np.prod(shp)), len(tasks), 900 + pi)):
+            tv[t][n] = d.view(shp).cuda()
+    masks = {}
+    if with_masks:
+        g = torch.Generator().manual_seed(4)
+        masks["blk.1.w"] = (torch.rand(shapes["blk.1.w"], generator=g) < 0.9).cuda()
+        masks["emb"] = (torch.rand(shapes["emb"], generator=g) < 0.2).cuda()
+    return tv, masks, {n: torch.Size(s) for n, s in shapes.items()}
+
+
+@pytest.mark.parametrize("with_masks,include_noise", [(False, False), (True, False), (True, True)])
+def test_batched_merge_is_the_per_parameter_merge(sq, with_masks, include_noise):
+    """merge_all_parameters / merge_with_clustering over the buffers of the fused run (two launches per plan: svdq_merge)
+    give, bit for bit, what the per-parameter route gives from the materialised payload dictionaries; a task that
+    lacks a parameter and non-uniform weights included."""
+    from oracle import svd_hybrid_oracle as orc
+    tasks = ["zeta", "alpha", "mid", "beta", "omega"]                       # insertion order != sorted order
+    tv, masks, shapes = _model_like(orc, tasks, with_masks)
+    del tv["mid"]["ln"]                                                     # one task lacks one parameter
+    cfg = sq.SVDHybridConfig(tasks=tasks, svd_energy_threshold=0.9, svd_max_rank=2, svd_low_bits=4, svd_rtvq_stages=3,
+                             svd_include_noise=include_noise, svd_noise_shrink=0.5, svd_min_mask_size=10)
+    weights = {"zeta": 0.4, "alpha": 0.1, "mid": 0.2, "beta": 0.05, "omega": 0.25}
+    bases, comp = sq.run_basis_and_compress(tv, masks, cfg, "cuda")
+    plain = {n: {t: dict(a) if a is not None else None for t, a in v.items()} for n, v in comp.items()}   # no batch handle
+    fast = sq.merge_all_parameters(comp, bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
+    from svdq_amd import merge as mg
+    assert len(mg._merge_batched(sorted(comp), comp, bases, masks, ([(weights, None)], None), shapes, cfg, "cuda")) \
+        == len(comp)                                                         # every parameter took the batched route
+    slow = sq.merge_all_parameters(plain, bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
+    assert sorted(fast) == sorted(slow) == sorted(shapes)
+    for n in shapes:
+        assert fast[n].shape == shapes[n] and torch.equal(fast[n], slow[n]), n
+        exact = sum(weights[t] * tv[t][n] for t in tasks if n in tv[t]) / sum(weights[t] for t in tasks if n in tv[t])
+        if n not in masks:
+            assert float((fast[n] - exact).norm() / exact.norm()) < 0.08, n
+    on_cpu = sq.merge_all_parameters(comp, bases, masks, weights, shapes, cfg, verbose=False)     # default device="cpu"
+    assert all(not v.is_cuda and torch.equal(v, fast[n].cpu()) for n, v in on_cpu.items())
+    assign = {"zeta": 1, "alpha": 0, "mid": 1, "beta": 0, "omega": 1}
+    cf = sq.merge_with_clustering(comp, bases, masks, weights, assign, shapes, cfg, device="cuda")
+    assert mg._merge_with_clustering_batched(comp, bases, masks, weights, {1: ["zeta", "mid", "omega"], 0: ["alpha", "beta"]},
+                                              shapes, cfg, "cuda") is not None
+    cs = sq.merge_with_clustering(plain, bases, masks, weights, assign, shapes, cfg, device="cuda")
+    for n in shapes:
+        assert torch.equal(cf[n], cs[n]), n
+
+
+def test_batched_diagnostics_match_per_parameter(sq):
+    """compute_all_diagnostics through svdq_diagnostics (one pass over U and the N deltas per plan) against the
+    per-(parameter, task) fused-error route: same dictionaries, numbers equal to the last digits of the fp64 sums."""
+    from oracle import svd_hybrid_oracle as orc
+    from svdq_amd import diagnostics as dg
+    tasks = ["t3", "t1", "t2", "t0"]
+    tv, masks, shapes = _model_like(orc, tasks, False)
+    tv = {t: {n: v.flatten() for n, v in d.items()} for t, d in tv.items()}      # resident flat tensors: the plan keeps them
+    cfg = sq.SVDHybridConfig(tasks=tasks, svd_energy_threshold=0.9, svd_max_rank=2, svd_low_bits=4, svd_rtvq_stages=2)
+    bases, comp = sq.run_basis_and_compress(tv, None, cfg, "cuda")
+    assert len(dg._batched_errors(tv, comp, bases, {})) == len(shapes)
+    fast = sq.compute_all_diagnostics(tv, comp, bases, {}, cfg, device="cuda")
+    plain = {n: {t: dict(a) for t, a in v.items()} for n, v in comp.items()}
+    slow = sq.compute_all_diagnostics(tv, plain, bases, {}, cfg, device="cuda")
+    assert list(fast["per_parameter"]) == list(slow["per_parameter"])
+    for n in shapes:
+        f, s = fast["per_parameter"][n], slow["per_parameter"][n]
+        assert list(f.keys()) == list(s.keys()) and f["basis"] == s["basis"] and f["original_shape"] == s["original_shape"]
+        assert int(f["masked_size"]) == int(s["masked_size"]) and f["compression_ratios"] == s["compression_ratios"]
+        assert list(f["reconstruction_errors"]) == list(s["reconstruction_errors"]) == tasks
+        for t in tasks:
+            for key, v in s["reconstruction_errors"][t].items():
+                assert f["reconstruction_errors"][t][key] == pytest.approx(v, rel=1e-6, abs=1e-12), (n, t, key)
+        for key in ("mean_relative_error", "std_relative_error", "max_relative_error", "min_relative_error"):
+            assert f[key] == pytest.approx(s[key], rel=1e-6, abs=1e-12)
+    for key, v in slow["summary"].items():
+        assert fast["summary"][key] == pytest.approx(v, rel=1e-6)
