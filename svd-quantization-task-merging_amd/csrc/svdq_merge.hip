@@ -90,8 +90,10 @@ __device__ __forceinline__ void lds_fence() {
 }
 
 // One wavefront per work unit of the plan; 256-row blocks; lane l owns rows l, 64 + l, 128 + l, 192 + l of a block (the
-// [256, k] / [256, nl] tiles arrive in LDS with 16-byte loads; a lane's row reads are then conflict-free).
-template <bool U16>
+// [256, k] / [256, nl] tiles arrive in LDS with 16-byte loads; a lane's row reads are then conflict-free).  Columns
+// outermost: one coefficient read serves the lane's four rows, and the four fma chains are independent.
+// NS = compiled-in number of sets (1, 2, 4, 8 >= n_sets).
+template <bool U16, int NS>
 __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__restrict__ params,
                                                           const SvdqUnit *__restrict__ units,
                                                           const int64_t *__restrict__ rows_dev, int NT, int n_sets,
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
     // dynamic LDS: [256 x N] basis elements (the U_high tile, then the U_low tile), then the coefficient sets
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     T *UT = reinterpret_cast<T *>(lds_raw);
-    float *C = reinterpret_cast<float *>(lds_raw + (size_t)SVDQ_BLK_ROWS * NT * ES);
-    float *SH = C + MRG_MAX_SETS * NT;
+    float *C = reinterpret_cast<float *>(lds_raw + (size_t)SVDQ_BLK_ROWS * NT * ES);   // [column][NS]
+    float *SH = C + NS * NT;
     const int lane = threadIdx.x;
     const SvdqUnit ud = units[blockIdx.x];
     const int p = ud.param;
@@ -120,8 +122,12 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
     if (r_end > D) r_end = D;
     if (r_begin >= r_end) return;
     const int k = k_in[p], r = r_in[p], nl = r - k, n = NT;
-    for (int e = lane; e < n_sets * n; e += 64) C[e] = cbar[(size_t)p * n_sets * n + e];
-    if (lane < n_sets) SH[lane] = set_share ? set_share[(per_param ? (size_t)p * n_sets : 0) + lane] : 1.f;
+    for (int e = lane; e < NS * n; e += 64) {      // transposed: the NS coefficients of a column side by side
+        const int i = e / NS, s = e % NS;
+        C[e] = s < n_sets ? cbar[((size_t)p * n_sets + s) * n + i] : 0.f;
+    }
+    if (lane < NS)
+        SH[lane] = (set_share && lane < n_sets) ? set_share[(per_param ? (size_t)p * n_sets : 0) + lane] : -1.f;
     const float scale = scale_tab ? scale_tab[p] : 1.f;
     const uint8_t *slab = basis + params[p].slab_off;
     const uint8_t *gUh = slab;
@@ -136,49 +142,58 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
         if (k > 0) copy_in(Uh, gUh + rb * (int64_t)k * ES, rows_blk * k * ES, lane);
         if (nl > 0) copy_in(Ul, gUl + rb * (int64_t)nl * ES, rows_blk * nl * ES, lane);
         float mv[4], bv[4];
+        int rl[4];      // the lane's rows, clamped into the block (results of clamped rows are not stored)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const int64_t row = rb + 64 * m + lane;
-            mv[m] = (gmean && row < D) ? gmean[row] : 0.f;
-            bv[m] = (gbase && row < D) ? gbase[row] : 0.f;
+            const int q = 64 * m + lane;
+            rl[m] = q < rows_blk ? q : rows_blk - 1;
+            mv[m] = gmean ? gmean[rb + rl[m]] : 0.f;
+            bv[m] = gbase ? gbase[rb + rl[m]] : 0.f;
         }
         lds_fence();
+        float hi[4][NS], lo[4][NS];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) hi[m][s] = lo[m][s] = 0.f;
+        for (int i = 0; i < k; ++i) {
+            float c[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) c[s] = C[i * NS + s];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float u = u_val(Uh, rl[m] * k + i);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) hi[m][s] = fmaf(u, c[s], hi[m][s]);
+            }
+        }
+        for (int j = 0; j < nl; ++j) {
+            float c[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) c[s] = C[(k + j) * NS + s];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float u = u_val(Ul, rl[m] * nl + j);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) lo[m][s] = fmaf(u, c[s], lo[m][s]);
+            }
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const int rl = 64 * m + lane;
-            if (rl < rows_blk) {
-                float hi[MRG_MAX_SETS], lo[MRG_MAX_SETS];
+            float res = 0.f;
 #pragma unroll
-                for (int s = 0; s < MRG_MAX_SETS; ++s) hi[s] = lo[s] = 0.f;
-                for (int i = 0; i < k; ++i) {
-                    const float u = u_val(Uh, rl * k + i);
-#pragma unroll
-                    for (int s = 0; s < MRG_MAX_SETS; ++s)
-                        if (s < n_sets) hi[s] = fmaf(u, C[s * n + i], hi[s]);
+            for (int s = 0; s < NS; ++s) {
+                float v = __fadd_rn(hi[m][s], lo[m][s]);
+                if (gmean) v = __fadd_rn(v, mv[m]);
+                v = __fmul_rn(v, scale);
+                if (set_share) {
+                    if (SH[s] >= 0.f) res = __fadd_rn(res, __fmul_rn(v, SH[s]));   // (stack * w).sum(0), set by set
+                } else if (s == 0) {
+                    res = v;
                 }
-                for (int j = 0; j < nl; ++j) {
-                    const float u = u_val(Ul, rl * nl + j);
-#pragma unroll
-                    for (int s = 0; s < MRG_MAX_SETS; ++s)
-                        if (s < n_sets) lo[s] = fmaf(u, C[s * n + k + j], lo[s]);
-                }
-                float res = 0.f;
-#pragma unroll
-                for (int s = 0; s < MRG_MAX_SETS; ++s) {
-                    if (s < n_sets) {
-                        float v = __fadd_rn(hi[s], lo[s]);
-                        if (gmean) v = __fadd_rn(v, mv[m]);
-                        v = __fmul_rn(v, scale);
-                        if (set_share) {
-                            if (SH[s] >= 0.f) res = __fadd_rn(res, __fmul_rn(v, SH[s]));   // (stack * w).sum(0), set by set
-                        } else {
-                            res = v;
-                        }
-                    }
-                }
-                if (gbase) res = __fadd_rn(bv[m], res);      // base + delta (merge.py:429-552)
-                gout[rb + rl] = res;
             }
+            if (gbase) res = __fadd_rn(bv[m], res);      // base + delta (merge.py:429-552)
+            if (64 * m + lane < rows_blk) gout[rb + 64 * m + lane] = res;
         }
         lds_fence();
     }
@@ -393,16 +408,29 @@ extern "C" int svdq_merge_reconstruct(const svdq_plan *pl, const int64_t *rows_d
     auto bp = reinterpret_cast<const float *const *>(base_ptrs);
     auto op = reinterpret_cast<float *const *>(out_ptrs);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)SVDQ_BLK_ROWS * pl->n_tasks * (pl->cfg.fp16 ? 2 : 4) +
-                       (size_t)(MRG_MAX_SETS * pl->n_tasks + MRG_MAX_SETS) * 4;
-    if (pl->cfg.fp16)
-        hipLaunchKernelGGL((k_merge_reconstruct<true>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params, pl->d_units,
-                           rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, reinterpret_cast<const uint8_t *>(basis),
-                           pl->cfg.center ? mean : nullptr, cbar, set_share, scale, bp, op);
-    else
-        hipLaunchKernelGGL((k_merge_reconstruct<false>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params, pl->d_units,
-                           rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, reinterpret_cast<const uint8_t *>(basis),
-                           pl->cfg.center ? mean : nullptr, cbar, set_share, scale, bp, op);
+    const int ns = n_sets == 1 ? 1 : (n_sets == 2 ? 2 : (n_sets <= 4 ? 4 : 8));
+    const size_t lds = (size_t)SVDQ_BLK_ROWS * pl->n_tasks * (pl->cfg.fp16 ? 2 : 4) + (size_t)(ns * pl->n_tasks + ns) * 4;
+    const uint8_t *bs = reinterpret_cast<const uint8_t *>(basis);
+    const float *mn = pl->cfg.center ? mean : nullptr;
+#define SVDQ_MRG_LAUNCH(F16, NS_)                                                                                      \
+    hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params, pl->d_units, \
+                       rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share, scale, bp, op)
+    if (pl->cfg.fp16) {
+        switch (ns) {
+            case 1: SVDQ_MRG_LAUNCH(true, 1); break;
+            case 2: SVDQ_MRG_LAUNCH(true, 2); break;
+            case 4: SVDQ_MRG_LAUNCH(true, 4); break;
+            default: SVDQ_MRG_LAUNCH(true, 8); break;
+        }
+    } else {
+        switch (ns) {
+            case 1: SVDQ_MRG_LAUNCH(false, 1); break;
+            case 2: SVDQ_MRG_LAUNCH(false, 2); break;
+            case 4: SVDQ_MRG_LAUNCH(false, 4); break;
+            default: SVDQ_MRG_LAUNCH(false, 8); break;
+        }
+    }
+#undef SVDQ_MRG_LAUNCH
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
