@@ -295,10 +295,17 @@ __device__ void eig_param(double *__restrict__ lds, int p, int tid, int64_t D,
         s_i0 = i0;
         // N > 16 accumulates fp32 products first: a sigma between the noise floor of the explicitly deflated null
         // direction (~1e-8 sigma_0) and 2e-2 sigma_0 may be off by more than rtol 2e-5 -> ask for the fp64 pass
+        // ... and so may one the fp32-product sums measured as NEGATIVE (clipped to sigma = 0 above): a true lambda up
+        // to ~1e-7 lambda_0 can come out below zero, and would then pass for a null direction.  A centred stack of
+        // D >= n rows has exactly one null direction (the deflated one), anything else none: every surplus
+        // direction at or below the noise floor asks for the fp64 pass too.
         if (refine_out) {
-            int need = 0;
+            int need = 0, nulls = 0;
             for (int i = 1; i < r; ++i)
                 if (sig[i] > 3e-7 * sig[0] && sig[i] < 2e-2 * sig[0]) need = 1;
+            for (int i = 0; i < r; ++i)
+                if (!(sig[i] > 3e-7 * sig[0])) ++nulls;
+            if (nulls > ((center && D >= (int64_t)n) ? 1 : 0) && sig[0] > 0.0) need = 1;
             refine_out[p] = need;
         }
     }

@@ -12,6 +12,15 @@
 //   mask_select(Tensor x, Tensor mask, bool invert) -> Tensor
 //   compress(Tensor[] deltas, int n_tasks, float energy, int max_rank, bool center, bool fp16, int bits, int stages)
 //       -> (Tensor small, Tensor basis, Tensor mean)          packed buffers: svdq_plan_small_layout / _basis_layout
+//   compress_masked(Tensor[] deltas, Tensor[] masks, int n_tasks, <settings>) -> (small, basis, mean, Tensor rows)
+//       masks[p] = the combined mask of parameter p; mask walk (svdq_compress_masked), N <= 16
+//   compress_gather(...same...)                                the same through int32 index lists (svdq_compress_gather)
+//   compress_from_base(Tensor[] finetuned, Tensor[] base, int n_tasks, <settings>) -> (small, basis, mean)
+//   mask_combine_indices(Tensor[] masks, int n_masks, str strategy) -> (Tensor[] combined, Tensor[] indices, Tensor counts)
+//   reconstruct(Tensor U_high, Tensor U_low, Tensor coef, Tensor? mean, float scale) -> Tensor
+//   recon_error(Tensor U_high, Tensor U_low, Tensor coef, Tensor? mean, Tensor orig) -> Tensor      (float64 [6])
+//   merge(Tensor small, Tensor basis, Tensor mean, int[] rows, int n_tasks, <settings>, Tensor weights, Tensor[] base)
+//       -> Tensor[]                                            svdq_merge on the buffers `compress` returned
 //   ingest(Tensor base, Tensor[] finetuned) -> Tensor[]
 //   task_gram(Tensor[] deltas, int n_tasks) -> Tensor
 //   plan_cache_size() -> int                                  plans kept by compress (for tests)
@@ -127,8 +136,12 @@ at::Tensor mask_combine(at::TensorList masks, c10::string_view strategy) {
     else if (strategy == "intersection") code = SVDQ_MASK_INTERSECTION;
     else if (strategy == "majority") code = SVDQ_MASK_MAJORITY;
     else TORCH_CHECK_VALUE(false, "Unknown mask strategy: ", std::string(strategy));
-    for (const at::Tensor &m : masks)
+    for (const at::Tensor &m : masks) {
         TORCH_CHECK_VALUE(m.sizes() == masks[0].sizes(), "Shape mismatch: mask ", m.sizes(), " vs mask ", masks[0].sizes());
+        // the kernel dereferences every mask from masks[0]'s device
+        TORCH_CHECK_VALUE(m.device() == masks[0].device(), "mask_combine: all masks must live on one device (got ",
+                          m.device(), " and ", masks[0].device(), ")");
+    }
     const c10::Device dev = masks[0].device();
     c10::DeviceGuard guard(dev);
     std::vector<at::Tensor> flat;
@@ -236,16 +249,8 @@ using PlanCache = std::list<std::pair<PlanKey, std::unique_ptr<Plan>>>;
 // most recently used last; never destroyed: at process exit the HIP runtime may be gone before static destructors run
 PlanCache &g_cache = *new PlanCache;
 
-std::tuple<at::Tensor, at::Tensor, at::Tensor> compress(at::TensorList deltas, int64_t n_tasks, double energy,
-                                                        int64_t max_rank, bool center, bool fp16, int64_t bits,
-                                                        int64_t stages) {
-    std::vector<at::Tensor> vecs = prep_list(deltas, n_tasks, "compress");
-    const c10::Device dev = vecs[0].device();
-    c10::DeviceGuard guard(dev);
-    void *stream = stream_of(dev);
-    PlanKey key{rows_of(vecs, n_tasks), n_tasks, max_rank, bits, stages, energy, center, fp16, (int)dev.index(), stream};
-
-    std::lock_guard<std::mutex> lock(g_cache_mu);
+// take the plan of `key` out of the cache (or make it); give it back with release_plan once the launches are enqueued
+std::unique_ptr<Plan> acquire_plan(const PlanKey &key, const c10::Device &dev) {
     std::unique_ptr<Plan> plan;
     for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
         if (it->first == key) {
@@ -255,32 +260,214 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> compress(at::TensorList deltas, i
         }
     if (!plan) {
         svdq_config cfg{};
-        cfg.energy_threshold = (float)energy;
-        cfg.max_rank = max_rank > 0 ? (int32_t)max_rank : 0;
-        cfg.center = center;
-        cfg.fp16 = fp16;
-        cfg.low_bits = (int32_t)bits;
-        cfg.rtvq_stages = (int32_t)stages;
-        plan = make_plan(key.rows, n_tasks, cfg, dev);
+        cfg.energy_threshold = (float)key.energy;
+        cfg.max_rank = key.max_rank > 0 ? (int32_t)key.max_rank : 0;
+        cfg.center = key.center;
+        cfg.fp16 = key.fp16;
+        cfg.low_bits = (int32_t)key.bits;
+        cfg.rtvq_stages = (int32_t)key.stages;
+        plan = make_plan(key.rows, key.n_tasks, cfg, dev);
         while (g_cache.size() >= kPlanCacheMax) {
             sync(g_cache.front().second->dev);                        // its tables may still be in use
             g_cache.pop_front();
         }
     }
-    // basis and mean in ONE allocation, the mean right behind the basis (pass-2 time depends on it: DESIGN.md section 5)
-    const int64_t bb = plan->sizes.basis_bytes, gap = (bb + 255) / 256 * 256;
-    const int64_t nm = center ? plan->sizes.mean_floats * 4 : 0;
+    return plan;
+}
+
+void release_plan(PlanKey key, std::unique_ptr<Plan> plan) { g_cache.emplace_back(std::move(key), std::move(plan)); }
+
+struct Outputs {
+    at::Tensor small, basis, mean;
+};
+
+// basis and mean in ONE allocation, the mean right behind the basis (pass-2 time depends on it: DESIGN.md section 5)
+Outputs alloc_outputs(const Plan &plan, bool center, const c10::Device &dev) {
+    const int64_t bb = plan.sizes.basis_bytes, gap = (bb + 255) / 256 * 256;
+    const int64_t nm = center ? plan.sizes.mean_floats * 4 : 0;
     at::Tensor out = bytes_on(dev, gap + nm);
-    at::Tensor basis = out.narrow(0, 0, bb);
-    at::Tensor mean = center ? out.narrow(0, gap, nm).view(at::kFloat) : floats_on(dev, 0);
-    at::Tensor small = at::zeros({plan->sizes.small_bytes}, at::TensorOptions().dtype(at::kByte).device(dev));
+    Outputs o;
+    o.basis = out.narrow(0, 0, bb);
+    o.mean = center ? out.narrow(0, gap, nm).view(at::kFloat) : floats_on(dev, 0);
+    o.small = at::zeros({plan.sizes.small_bytes}, at::TensorOptions().dtype(at::kByte).device(dev));
+    return o;
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> compress(at::TensorList deltas, int64_t n_tasks, double energy,
+                                                        int64_t max_rank, bool center, bool fp16, int64_t bits,
+                                                        int64_t stages) {
+    std::vector<at::Tensor> vecs = prep_list(deltas, n_tasks, "compress");
+    const c10::Device dev = vecs[0].device();
+    c10::DeviceGuard guard(dev);
+    void *stream = stream_of(dev);
+    PlanKey key{rows_of(vecs, n_tasks), n_tasks, max_rank, bits, stages, energy, center, fp16, (int)dev.index(), stream};
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    std::unique_ptr<Plan> plan = acquire_plan(key, dev);
+    Outputs o = alloc_outputs(*plan, center, dev);
     at::Tensor table = table_of(vecs, dev);
-    const int rc = svdq_compress(plan->h, table.data_ptr(), nullptr, plan->workspace.data_ptr(), small.data_ptr(),
-                                 basis.data_ptr(), center ? mean.data_ptr<float>() : nullptr, stream);
-    g_cache.emplace_back(std::move(key), std::move(plan));
+    const int rc = svdq_compress(plan->h, table.data_ptr(), nullptr, plan->workspace.data_ptr(), o.small.data_ptr(),
+                                 o.basis.data_ptr(), center ? o.mean.data_ptr<float>() : nullptr, stream);
+    release_plan(std::move(key), std::move(plan));
     check(rc, "svdq_compress");
     // inputs and the table are only read by the kernels just enqueued; temporaries are released stream-ordered
-    return {small, basis, mean};
+    return {o.small, o.basis, o.mean};
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> compress_from_base(at::TensorList finetuned, at::TensorList base,
+                                                                  int64_t n_tasks, double energy, int64_t max_rank,
+                                                                  bool center, bool fp16, int64_t bits, int64_t stages) {
+    std::vector<at::Tensor> vecs = prep_list(finetuned, n_tasks, "compress_from_base");
+    const c10::Device dev = vecs[0].device();
+    c10::DeviceGuard guard(dev);
+    void *stream = stream_of(dev);
+    std::vector<int64_t> rows = rows_of(vecs, n_tasks);
+    TORCH_CHECK_VALUE(base.size() == rows.size(), "compress_from_base: one base tensor per parameter");
+    std::vector<at::Tensor> bs;
+    for (size_t p = 0; p < rows.size(); ++p) {
+        TORCH_CHECK_VALUE(base[p].device() == dev, "compress_from_base: all tensors must live on one device");
+        TORCH_CHECK_VALUE(base[p].numel() == rows[p], "parameter ", p, ": base and fine-tuned tensors differ in size");
+        bs.push_back(prep(base[p]));
+    }
+    PlanKey key{rows, n_tasks, max_rank, bits, stages, energy, center, fp16, (int)dev.index(), stream};
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    std::unique_ptr<Plan> plan = acquire_plan(key, dev);
+    Outputs o = alloc_outputs(*plan, center, dev);
+    at::Tensor table = table_of(vecs, dev), btab = table_of(bs, dev);
+    const int rc = svdq_compress_from_base(plan->h, table.data_ptr(), btab.data_ptr(), nullptr, plan->workspace.data_ptr(),
+                                           o.small.data_ptr(), o.basis.data_ptr(),
+                                           center ? o.mean.data_ptr<float>() : nullptr, stream);
+    release_plan(std::move(key), std::move(plan));
+    check(rc, "svdq_compress_from_base");
+    return {o.small, o.basis, o.mean};
+}
+
+// masked parameters: masks[p] = the combined mask of parameter p (bool / uint8, the parameter's shape).
+// walk = true: svdq_maskset_count_scan + _unit_starts + svdq_compress_masked (no index lists; N <= 16);
+// walk = false: svdq_maskset_indices + svdq_compress_gather.  rows (int64 [P], device) = mask.sum() per parameter.
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> compress_with_masks(at::TensorList deltas, at::TensorList masks,
+                                                                               int64_t n_tasks, double energy,
+                                                                               int64_t max_rank, bool center, bool fp16,
+                                                                               int64_t bits, int64_t stages, bool walk,
+                                                                               const char *what) {
+    std::vector<at::Tensor> vecs = prep_list(deltas, n_tasks, what);
+    const c10::Device dev = vecs[0].device();
+    c10::DeviceGuard guard(dev);
+    void *stream = stream_of(dev);
+    std::vector<int64_t> rows = rows_of(vecs, n_tasks);
+    const int64_t P = (int64_t)rows.size();
+    TORCH_CHECK_VALUE((int64_t)masks.size() == P, what, ": one combined mask per parameter");
+    std::vector<at::Tensor> mb;
+    for (int64_t p = 0; p < P; ++p) {
+        TORCH_CHECK_VALUE(masks[p].device() == dev, what, ": all tensors must live on one device");
+        TORCH_CHECK_VALUE(masks[p].numel() == rows[p], "Shape mismatch: tensor vs mask for parameter ", p);
+        mb.push_back(mask_bytes(masks[p]));
+    }
+    svdq_maskset *ms = nullptr;
+    check(svdq_maskset_create(&ms, (int32_t)P, rows.data()), "svdq_maskset_create");
+    struct Guard {
+        svdq_maskset *m;
+        c10::Device d;
+        ~Guard() {
+            sync(d);      // its device tables are read by the launches below
+            svdq_maskset_destroy(m);
+        }
+    } ms_guard{ms, dev};
+    at::Tensor work = bytes_on(dev, svdq_maskset_work_bytes(ms));
+    at::Tensor ct = at::zeros({P}, at::TensorOptions().dtype(at::kLong).device(dev));
+    at::Tensor mtab = table_of(mb, dev);
+    PlanKey key{rows, n_tasks, max_rank, bits, stages, energy, center, fp16, (int)dev.index(), stream};
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    std::unique_ptr<Plan> plan = acquire_plan(key, dev);
+    Outputs o = alloc_outputs(*plan, center, dev);
+    at::Tensor table = table_of(vecs, dev);
+    int rc;
+    if (walk) {
+        at::Tensor us = at::empty({plan->sizes.n_units}, at::TensorOptions().dtype(at::kLong).device(dev));
+        rc = svdq_maskset_count_scan(ms, mtab.data_ptr(), ct.data_ptr<int64_t>(), nullptr, work.data_ptr(), stream);
+        if (rc == SVDQ_OK)
+            rc = svdq_maskset_unit_starts(ms, plan->h, mtab.data_ptr(), nullptr, ct.data_ptr<int64_t>(), work.data_ptr(),
+                                          us.data_ptr<int64_t>(), stream);
+        if (rc == SVDQ_OK)
+            rc = svdq_compress_masked(plan->h, table.data_ptr(), mtab.data_ptr(), us.data_ptr<int64_t>(),
+                                      ct.data_ptr<int64_t>(), plan->workspace.data_ptr(), o.small.data_ptr(),
+                                      o.basis.data_ptr(), center ? o.mean.data_ptr<float>() : nullptr, stream);
+    } else {
+        std::vector<at::Tensor> idx;
+        for (int64_t p = 0; p < P; ++p) idx.push_back(at::empty({rows[p]}, at::TensorOptions().dtype(at::kInt).device(dev)));
+        at::Tensor itab = table_of(idx, dev);
+        rc = svdq_maskset_indices(ms, mtab.data_ptr(), itab.data_ptr(), nullptr, ct.data_ptr<int64_t>(), nullptr,
+                                  work.data_ptr(), stream);
+        if (rc == SVDQ_OK)
+            rc = svdq_compress_gather(plan->h, table.data_ptr(), itab.data_ptr(), ct.data_ptr<int64_t>(),
+                                      plan->workspace.data_ptr(), o.small.data_ptr(), o.basis.data_ptr(),
+                                      center ? o.mean.data_ptr<float>() : nullptr, stream);
+        sync(dev);      // the index lists die with this scope
+    }
+    release_plan(std::move(key), std::move(plan));
+    check(rc, what);
+    return {o.small, o.basis, o.mean, ct};
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> compress_masked(at::TensorList deltas, at::TensorList masks,
+                                                                           int64_t n_tasks, double energy,
+                                                                           int64_t max_rank, bool center, bool fp16,
+                                                                           int64_t bits, int64_t stages) {
+    return compress_with_masks(deltas, masks, n_tasks, energy, max_rank, center, fp16, bits, stages, true,
+                               "compress_masked");
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> compress_gather(at::TensorList deltas, at::TensorList masks,
+                                                                           int64_t n_tasks, double energy,
+                                                                           int64_t max_rank, bool center, bool fp16,
+                                                                           int64_t bits, int64_t stages) {
+    return compress_with_masks(deltas, masks, n_tasks, energy, max_rank, center, fp16, bits, stages, false,
+                               "compress_gather");
+}
+
+// svdq_merge on the buffers `compress` returned for the same rows / settings: merged delta of every parameter
+// (weights float32 [n_tasks] or [n_sets, n_tasks] with shares = uniform over sets when more than one), + base when given
+std::vector<at::Tensor> merge(const at::Tensor &small, const at::Tensor &basis, const at::Tensor &mean,
+                              at::IntArrayRef rows_in, int64_t n_tasks, double energy, int64_t max_rank, bool center,
+                              bool fp16, int64_t bits, int64_t stages, const at::Tensor &weights, at::TensorList base) {
+    TORCH_CHECK(small.is_cuda() && basis.is_cuda(), "svdq operators take device tensors");
+    const c10::Device dev = small.device();
+    c10::DeviceGuard guard(dev);
+    void *stream = stream_of(dev);
+    std::vector<int64_t> rows(rows_in.begin(), rows_in.end());
+    const int64_t P = (int64_t)rows.size();
+    TORCH_CHECK_VALUE(P >= 1, "Empty delta list");
+    TORCH_CHECK_VALUE(base.empty() || (int64_t)base.size() == P, "merge: one base tensor per parameter, or none");
+    at::Tensor w = weights.to(dev, at::kFloat).contiguous();
+    TORCH_CHECK_VALUE((w.dim() == 1 || w.dim() == 2) && w.size(-1) == n_tasks, "merge: weights are [n_tasks] or [n_sets, n_tasks]");
+    const int64_t n_sets = w.dim() == 2 ? w.size(0) : 1;
+    PlanKey key{rows, n_tasks, max_rank, bits, stages, energy, center, fp16, (int)dev.index(), stream};
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    std::unique_ptr<Plan> plan = acquire_plan(key, dev);
+    TORCH_CHECK_VALUE(small.numel() == plan->sizes.small_bytes && basis.numel() >= plan->sizes.basis_bytes,
+                      "merge: small / basis are not the buffers of a plan with these rows and settings");
+    std::vector<at::Tensor> outs, bs;
+    for (int64_t p = 0; p < P; ++p) outs.push_back(floats_on(dev, rows[p]));
+    for (size_t p = 0; p < base.size(); ++p) {
+        TORCH_CHECK_VALUE(base[p].numel() == rows[p] && base[p].device() == dev, "merge: base tensor ", p, " does not match");
+        bs.push_back(prep(base[p]));
+    }
+    at::Tensor otab = table_of(outs, dev), btab = bs.empty() ? at::Tensor() : table_of(bs, dev);
+    at::Tensor share;
+    if (n_sets > 1) share = at::full({n_sets}, 1.0 / (double)n_sets, at::TensorOptions().dtype(at::kFloat).device(dev));
+    at::Tensor work = bytes_on(dev, svdq_merge_work_bytes(plan->h, (int32_t)n_sets));
+    const int64_t rows_off = [&] {
+        svdq_small_layout L{};
+        svdq_plan_small_layout(plan->h, &L);
+        return L.rows_off;
+    }();
+    const int rc = svdq_merge(plan->h, reinterpret_cast<const int64_t *>(small.data_ptr<uint8_t>() + rows_off),
+                              small.data_ptr(), basis.data_ptr(), (center && mean.numel() > 0) ? mean.data_ptr<float>() : nullptr,
+                              w.data_ptr<float>(), nullptr, (int32_t)n_sets, 0,
+                              n_sets > 1 ? share.data_ptr<float>() : nullptr, nullptr,
+                              bs.empty() ? nullptr : btab.data_ptr(), otab.data_ptr(), work.data_ptr(), stream);
+    release_plan(std::move(key), std::move(plan));
+    check(rc, "svdq_merge");
+    return outs;
 }
 
 int64_t plan_cache_size() {
@@ -337,6 +524,112 @@ at::Tensor task_gram(at::TensorList deltas, int64_t n_tasks) {
     return G;
 }
 
+// combine_masks + the flat[mask] index lists, batched over Q parameters (masks parameter-major, n_masks per parameter)
+std::tuple<std::vector<at::Tensor>, std::vector<at::Tensor>, at::Tensor> mask_combine_indices(at::TensorList masks,
+                                                                                              int64_t n_masks,
+                                                                                              c10::string_view strategy) {
+    TORCH_CHECK_VALUE(n_masks >= 1 && !masks.empty(), "Empty mask list");
+    TORCH_CHECK_VALUE((int64_t)masks.size() % n_masks == 0, "mask_combine_indices: n_masks masks per parameter");
+    int32_t code;
+    if (strategy == "union") code = SVDQ_MASK_UNION;
+    else if (strategy == "intersection") code = SVDQ_MASK_INTERSECTION;
+    else if (strategy == "majority") code = SVDQ_MASK_MAJORITY;
+    else TORCH_CHECK_VALUE(false, "Unknown mask strategy: ", std::string(strategy));
+    const c10::Device dev = masks[0].device();
+    c10::DeviceGuard guard(dev);
+    void *stream = stream_of(dev);
+    const int64_t Q = (int64_t)masks.size() / n_masks;
+    std::vector<int64_t> numel(Q);
+    std::vector<at::Tensor> flat, outs, idx;
+    for (int64_t q = 0; q < Q; ++q) {
+        numel[q] = masks[q * n_masks].numel();
+        TORCH_CHECK_VALUE(numel[q] >= 1, "mask_combine_indices: empty mask");
+        for (int64_t m = 0; m < n_masks; ++m) {
+            const at::Tensor &t = masks[q * n_masks + m];
+            TORCH_CHECK_VALUE(t.device() == dev, "mask_combine_indices: all masks must live on one device");
+            TORCH_CHECK_VALUE(t.sizes() == masks[q * n_masks].sizes(), "Shape mismatch: mask ", t.sizes(), " vs mask ",
+                              masks[q * n_masks].sizes());
+            flat.push_back(mask_bytes(t));
+        }
+        outs.push_back(bytes_on(dev, numel[q]));
+        idx.push_back(at::empty({numel[q]}, at::TensorOptions().dtype(at::kInt).device(dev)));
+    }
+    svdq_maskset *ms = nullptr;
+    check(svdq_maskset_create(&ms, (int32_t)Q, numel.data()), "svdq_maskset_create");
+    at::Tensor work = bytes_on(dev, svdq_maskset_work_bytes(ms));
+    at::Tensor ct = at::zeros({Q}, at::TensorOptions().dtype(at::kLong).device(dev));
+    at::Tensor mt = table_of(flat, dev), ot = table_of(outs, dev), it = table_of(idx, dev);
+    const int rc = svdq_maskset_combine_indices(ms, mt.data_ptr(), (int32_t)n_masks, code, ot.data_ptr(), it.data_ptr(),
+                                                nullptr, ct.data_ptr<int64_t>(), nullptr, work.data_ptr(), stream);
+    sync(dev);                                         // the set's device tables go away with it
+    svdq_maskset_destroy(ms);
+    check(rc, "svdq_maskset_combine_indices");
+    for (int64_t q = 0; q < Q; ++q) outs[q] = outs[q].view(at::kBool).view(masks[q * n_masks].sizes());
+    return {outs, idx, ct};
+}
+
+struct BasisArgs {
+    at::Tensor uh, ul, coef, mean;
+    int64_t rows = 0, k = 0, nl = 0;
+    bool fp16 = false;
+    c10::Device dev{c10::kCUDA, 0};
+};
+
+BasisArgs basis_args(const at::Tensor &U_high, const at::Tensor &U_low, const at::Tensor &coef,
+                     const c10::optional<at::Tensor> &mean, const char *what) {
+    TORCH_CHECK(U_high.is_cuda() && U_low.is_cuda(), "svdq operators take device tensors");
+    TORCH_CHECK_VALUE(U_high.dim() == 2 && U_low.dim() == 2 && U_high.size(0) == U_low.size(0), what,
+                      ": U_high [D, k] and U_low [D, n_low]");
+    BasisArgs a;
+    a.dev = U_high.device();
+    a.rows = U_high.size(0);
+    a.k = U_high.size(1);
+    a.nl = U_low.size(1);
+    TORCH_CHECK_VALUE(a.k + a.nl <= 32, what, ": at most 32 basis columns");
+    a.fp16 = (a.k ? U_high : U_low).scalar_type() == at::kHalf;
+    const auto dt = a.fp16 ? at::kHalf : at::kFloat;
+    a.uh = U_high.to(dt).contiguous();
+    a.ul = U_low.to(a.dev, dt).contiguous();
+    a.coef = coef.to(a.dev, at::kFloat).reshape({-1}).contiguous();
+    TORCH_CHECK_VALUE(a.coef.numel() == a.k + a.nl, "Shape mismatch: ", a.coef.numel(), " coefficients for ", a.k + a.nl,
+                      " basis columns");
+    if (mean.has_value() && mean->defined()) {
+        a.mean = prep(mean->to(a.dev));
+        TORCH_CHECK_VALUE(a.mean.numel() == a.rows, what, ": mean has ", a.mean.numel(), " elements, the basis ", a.rows, " rows");
+    }
+    return a;
+}
+
+at::Tensor reconstruct(const at::Tensor &U_high, const at::Tensor &U_low, const at::Tensor &coef,
+                       const c10::optional<at::Tensor> &mean, double scale) {
+    BasisArgs a = basis_args(U_high, U_low, coef, mean, "reconstruct");
+    c10::DeviceGuard guard(a.dev);
+    at::Tensor out = floats_on(a.dev, a.rows);
+    if (a.rows > 0)
+        check(svdq_reconstruct(a.k ? a.uh.data_ptr() : nullptr, a.nl ? a.ul.data_ptr() : nullptr, a.fp16, a.rows,
+                               (int32_t)a.k, (int32_t)a.nl, a.coef.data_ptr<float>(),
+                               a.mean.defined() ? a.mean.data_ptr<float>() : nullptr, (float)scale, out.data_ptr<float>(),
+                               stream_of(a.dev)),
+              "svdq_reconstruct");
+    return out;
+}
+
+at::Tensor recon_error(const at::Tensor &U_high, const at::Tensor &U_low, const at::Tensor &coef,
+                       const c10::optional<at::Tensor> &mean, const at::Tensor &orig) {
+    BasisArgs a = basis_args(U_high, U_low, coef, mean, "recon_error");
+    c10::DeviceGuard guard(a.dev);
+    at::Tensor x = prep(orig.to(a.dev));
+    TORCH_CHECK_VALUE(x.numel() == a.rows && a.rows >= 1, "Shape mismatch: original has ", x.numel(), " elements, the basis ",
+                      a.rows, " rows");
+    at::Tensor out = at::empty({6}, at::TensorOptions().dtype(at::kDouble).device(a.dev));
+    at::Tensor work = bytes_on(a.dev, svdq_recon_error_work_bytes(a.rows));
+    check(svdq_recon_error(a.k ? a.uh.data_ptr() : nullptr, a.nl ? a.ul.data_ptr() : nullptr, a.fp16, a.rows, (int32_t)a.k,
+                           (int32_t)a.nl, a.coef.data_ptr<float>(), a.mean.defined() ? a.mean.data_ptr<float>() : nullptr,
+                           nullptr, x.data_ptr<float>(), out.data_ptr<double>(), work.data_ptr(), stream_of(a.dev)),
+          "svdq_recon_error");
+    return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(svdq, m) {
@@ -346,6 +639,17 @@ TORCH_LIBRARY(svdq, m) {
     m.def("mask_select(Tensor x, Tensor mask, bool invert) -> Tensor");
     m.def("compress(Tensor[] deltas, int n_tasks, float energy, int max_rank, bool center, bool fp16, int bits, "
           "int stages) -> (Tensor, Tensor, Tensor)");
+    m.def("compress_masked(Tensor[] deltas, Tensor[] masks, int n_tasks, float energy, int max_rank, bool center, bool fp16, "
+          "int bits, int stages) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("compress_gather(Tensor[] deltas, Tensor[] masks, int n_tasks, float energy, int max_rank, bool center, bool fp16, "
+          "int bits, int stages) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("compress_from_base(Tensor[] finetuned, Tensor[] base, int n_tasks, float energy, int max_rank, bool center, "
+          "bool fp16, int bits, int stages) -> (Tensor, Tensor, Tensor)");
+    m.def("mask_combine_indices(Tensor[] masks, int n_masks, str strategy) -> (Tensor[], Tensor[], Tensor)");
+    m.def("reconstruct(Tensor U_high, Tensor U_low, Tensor coef, Tensor? mean, float scale) -> Tensor");
+    m.def("recon_error(Tensor U_high, Tensor U_low, Tensor coef, Tensor? mean, Tensor orig) -> Tensor");
+    m.def("merge(Tensor small, Tensor basis, Tensor mean, int[] rows, int n_tasks, float energy, int max_rank, bool center, "
+          "bool fp16, int bits, int stages, Tensor weights, Tensor[] base) -> Tensor[]");
     m.def("ingest(Tensor base, Tensor[] finetuned) -> Tensor[]");
     m.def("task_gram(Tensor[] deltas, int n_tasks) -> Tensor");
     m.def("plan_cache_size() -> int", plan_cache_size);
@@ -358,6 +662,13 @@ TORCH_LIBRARY_IMPL(svdq, CUDA, m) {
     m.impl("mask_combine", mask_combine);
     m.impl("mask_select", mask_select);
     m.impl("compress", compress);
+    m.impl("compress_masked", compress_masked);
+    m.impl("compress_gather", compress_gather);
+    m.impl("compress_from_base", compress_from_base);
+    m.impl("mask_combine_indices", mask_combine_indices);
+    m.impl("reconstruct", reconstruct);
+    m.impl("recon_error", recon_error);
+    m.impl("merge", merge);
     m.impl("ingest", ingest);
     m.impl("task_gram", task_gram);
 }

@@ -12,6 +12,14 @@ ATen arithmetic and no CPU implementation behind them.
     svdq::mask_select(Tensor x, Tensor mask, bool invert) -> Tensor
     svdq::compress(Tensor[] deltas, int n_tasks, float energy, int max_rank, bool center, bool fp16,
                    int bits, int stages) -> (Tensor small, Tensor basis, Tensor mean)
+    svdq::compress_masked(Tensor[] deltas, Tensor[] masks, int n_tasks, <the six settings>) -> (small, basis, mean, rows)
+    svdq::compress_gather(...same...)            the same through int32 index lists (sparse masks, N > 16)
+    svdq::compress_from_base(Tensor[] finetuned, Tensor[] base, int n_tasks, <settings>) -> (small, basis, mean)
+    svdq::mask_combine_indices(Tensor[] masks, int n_masks, str strategy) -> (Tensor[] combined, Tensor[] idx, Tensor counts)
+    svdq::reconstruct(Tensor U_high, Tensor U_low, Tensor coef, Tensor? mean, float scale) -> Tensor
+    svdq::recon_error(Tensor U_high, Tensor U_low, Tensor coef, Tensor? mean, Tensor orig) -> Tensor
+    svdq::merge(Tensor small, Tensor basis, Tensor mean, int[] rows, int n_tasks, <settings>, Tensor weights,
+                Tensor[] base) -> Tensor[]
     svdq::ingest(Tensor base, Tensor[] finetuned) -> Tensor[]
     svdq::task_gram(Tensor[] deltas, int n_tasks) -> Tensor
     svdq::plan_cache_size() -> int

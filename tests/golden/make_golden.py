@@ -789,6 +789,19 @@ def _structured(D, N, sigmas, seed, common_mean=0.0):
     return [torch.from_numpy(np.ascontiguousarray(T[:, j]).astype(np.float32)) for j in range(N)]
 
 
+def _structured_centred(D, N, sigmas, seed, common_mean):
+    """T = Q diag(sigmas) Z^T + c 1^T with the N - 1 columns of Z orthonormal AND orthogonal to the ones vector, so that
+    the CENTRED stack has exactly the singular values given (N - 1 of them) and the common offset c is what centring
+    removes."""
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, N - 1)))
+    M = np.concatenate([np.ones((N, 1)), rng.standard_normal((N, N - 1))], axis=1)
+    Zf, _ = np.linalg.qr(M)
+    Z = Zf[:, 1:]                      # orthonormal complement of 1 / sqrt(N)
+    T = (Q * np.asarray(sigmas, dtype=np.float64)) @ Z.T + common_mean * rng.standard_normal((D, 1))
+    return [torch.from_numpy(np.ascontiguousarray(T[:, j]).astype(np.float32)) for j in range(N)]
+
+
 def _s64(deltas, center):
     """fp64 singular values of exactly the matrix the reference factorises (fp32 stack, fp32 centring)."""
     T = torch.stack(deltas, dim=1)
@@ -820,11 +833,26 @@ def gen_spectrum():
     for tag, e1 in (("below", 0.29995), ("above", 0.30005)):
         en = [0.6, e1, 0.05 + (0.3 - e1), 0.03, 0.01, 0.006, 0.003, 0.001]
         specs.append((f"spectrum_thresh_{tag}_n8", _structured(6000, 8, np.sqrt(en), 106), 0.9, False))
+    _save_spectrum_specs(specs)
+
+
+def _save_spectrum_specs(specs):
     for name, deltas, thr, center in specs:
         out = basis_chain(deltas, thr, None, center, True, 4, 2, store_inputs=True, store_full=True)
         out["S_f64"] = _s64(deltas, center)
         save(name + ".npz", **out)
         print("   S  ", out["S"], " k", int(out["k"]), " energy", float(out["energy_retained"]))
+
+
+def gen_spectrum_gap():
+    """N > 16 with ONE singular value near 1e-4 sigma_0 behind a gap: lambda = 1e-8 lambda_0 lies below
+    what fp32-product sums resolve, so the first-pass Gram may measure it as negative (clipped to sigma = 0) -- the
+    refinement trigger must fire on the surplus null direction, not only on the (3e-7, 2e-2) sigma_0 band.  Two
+    seeds, centred and not, so that both signs of the first-pass noise are likely to occur."""
+    tail = [1.0, 0.8, 0.65, 0.5, 0.4, 0.32, 0.25, 0.2, 0.16, 0.13, 0.1, 0.085, 0.07, 0.06, 0.05, 0.045, 0.04, 0.035, 0.03]
+    specs = [("spectrum_gap_n20a", _structured(5000, 20, tail + [1.0e-4], 108), 0.9999, False),
+             ("spectrum_gap_n20b", _structured_centred(5000, 20, tail[:18] + [1.3e-4], 109, 0.2), 0.9999, True)]
+    _save_spectrum_specs(specs)
 
 # ------------------------------------------------------------------------------- rank KATs
 def gen_rank():
@@ -901,6 +929,7 @@ if __name__ == "__main__":
     gen_rank()
     gen_basis()
     gen_spectrum()
+    gen_spectrum_gap()
     gen_config1()
     gen_masks()
     gen_pipeline()

@@ -284,7 +284,8 @@ def test_basis_chain_vs_reference_vectors(sq, orc, name):
 
 # ------------------------------------------------------------------------------- small singular values
 SPECTRUM_FIXTURES = ["spectrum_graded_n8", "spectrum_graded_n8c", "spectrum_graded_n16", "spectrum_graded_n20", "spectrum_rankdef_n6",
-                     "spectrum_twins_n6c", "spectrum_thresh_below_n8", "spectrum_thresh_above_n8"]
+                     "spectrum_twins_n6c", "spectrum_thresh_below_n8", "spectrum_thresh_above_n8", "spectrum_gap_n20a",
+                     "spectrum_gap_n20b"]
 
 
 @pytest.mark.parametrize("name", SPECTRUM_FIXTURES)

@@ -5,7 +5,9 @@ import torch
 
 import svdq_amd  # noqa: F401  (registers the operators when the libraries are already built)
 
-OPS = ("rtvq_quantize", "rtvq_dequantize", "mask_combine", "mask_select", "compress", "ingest", "task_gram")
+OPS = ("rtvq_quantize", "rtvq_dequantize", "mask_combine", "mask_select", "compress", "ingest", "task_gram",
+       "compress_masked", "compress_gather", "compress_from_base", "mask_combine_indices", "reconstruct", "recon_error",
+       "merge")
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -97,3 +99,81 @@ def test_ops_match_the_python_layer():
     G = torch.ops.svdq.task_gram([v for vs in vecs for v in vs], N)
     ref = sum(torch.stack(vs).double() @ torch.stack(vs).double().T for vs in vecs)
     assert torch.allclose(G, ref, rtol=2e-6, atol=2e-6 * float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+def test_masked_from_base_and_consumer_ops_match_the_ctypes_route():
+    """compress_masked / compress_gather / compress_from_base / mask_combine_indices / reconstruct / recon_error / merge:
+    every operator against the same entry point reached through ctypes (svdq_amd.pipeline), bit for bit."""
+    from oracle import svd_hybrid_oracle as orc
+    from svdq_amd.pipeline import CompressPlan
+    from svdq_amd.mask_loader import MaskSet
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(8)
+    N, sizes = 6, [70001, 777, 4096 * 5]
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 60 + i)] for i, D in enumerate(sizes)]
+    flat = [v for vs in vecs for v in vs]
+    masks = [(torch.rand(D, generator=g) < 0.85).to(dev) for D in sizes]
+    kw = dict(energy_threshold=0.9, max_rank=None, center=True, fp16=True, low_bits=4, rtvq_stages=2, device=dev)
+    ms = MaskSet(sizes, dev)
+    ct, _ = ms.count_scan(masks)
+    mtab = torch.tensor([m.data_ptr() for m in ms._s["mb"]], dtype=torch.int64).to(dev)
+    ref = CompressPlan(sizes, N, **kw)
+    ref.run_masked(ref.pointer_table(vecs), mtab, ms.unit_starts(ref, ct), ct)
+    torch.cuda.synchronize()
+
+    def same_artifacts(small, basis, mean, plan):
+        assert torch.equal(small, plan.small)
+        sm = plan.fetch_small()
+        for p in range(len(sizes)):
+            rows, k, r = int(sm.rows[p]), int(sm.k[p]), int(sm.r[p])
+            a = plan.basis_tensors(p, k, r, rows)
+            lo = plan.slab_off[p]
+            assert torch.equal(basis[lo:lo + a[0].numel() * 2].view(torch.float16).view(a[0].shape), a[0])
+            o = plan.mean_off[p]
+            assert torch.equal(mean[o:o + rows], a[2].flatten())
+    for op in (torch.ops.svdq.compress_masked, torch.ops.svdq.compress_gather):
+        small, basis, mean, rows = op(flat, masks, N, 0.9, 0, True, True, 4, 2)
+        torch.cuda.synchronize()
+        assert torch.equal(rows, ct)
+        same_artifacts(small, basis, mean, ref)
+    with pytest.raises(ValueError, match="Shape mismatch"):
+        torch.ops.svdq.compress_masked(flat, [masks[0], masks[1], masks[2][:5]], N, 0.9, 0, True, True, 4, 2)
+    # straight from checkpoints
+    base = [torch.randn(D, generator=g).to(dev) for D in sizes]
+    ft = [[base[p] + vecs[p][t] for t in range(N)] for p in range(len(sizes))]
+    fb = CompressPlan(sizes, N, **kw)
+    fb.run_from_base(fb.pointer_table(ft), torch.tensor([b.data_ptr() for b in base], dtype=torch.int64).to(dev))
+    small, basis, mean = torch.ops.svdq.compress_from_base([f for fs in ft for f in fs], base, N, 0.9, 0, True, True, 4, 2)
+    torch.cuda.synchronize()
+    same_artifacts(small, basis, mean, fb)
+    # combine + index lists
+    per_task = [[(torch.rand(D, generator=g) > 0.6).to(dev) for _ in range(3)] for D in sizes]
+    comb, idx, cnt = torch.ops.svdq.mask_combine_indices([m for ms_ in per_task for m in ms_], 3, "majority")
+    for q, D in enumerate(sizes):
+        want = torch.stack([m.int() for m in per_task[q]]).sum(0) * 2 >= 3
+        assert torch.equal(comb[q], want) and int(cnt[q]) == int(want.sum())
+        assert torch.equal(idx[q][:int(cnt[q])].long(), torch.nonzero(want).flatten())
+    # consumers of one basis
+    sm = fb.fetch_small()
+    k, r = int(sm.k[0]), int(sm.r[0])
+    Uh, Ul, mu = fb.basis_tensors(0, k, r, sizes[0])
+    coef = torch.randn(r, generator=g).to(dev)
+    import svdq_amd
+    want = svdq_amd.merge._reconstruct(coef[:k], coef[k:], Uh, Ul, mu, 0.5)
+    assert torch.equal(torch.ops.svdq.reconstruct(Uh, Ul, coef, mu, 0.5), want)
+    assert torch.equal(torch.ops.svdq.reconstruct(Uh, Ul, coef, None, 1.0), svdq_amd.merge._reconstruct(coef[:k], coef[k:], Uh, Ul, None, 1.0))
+    x = ft[0][2] - base[0]
+    e6 = torch.ops.svdq.recon_error(Uh, Ul, coef, None, x)
+    ref6 = svdq_amd.diagnostics._fused_error(x, Uh, Ul, coef[:k], coef[k:], dev)
+    assert [float(v) for v in e6.cpu()] == [ref6[key] for key in svdq_amd.diagnostics._KEYS]
+    # the plan-level merge on the buffers the compress operator returned
+    w = torch.tensor([0.3, 0.1, 0.2, 0.15, 0.05, 0.2], device=dev)
+    outs = torch.ops.svdq.merge(small, basis, mean, sizes, N, 0.9, 0, True, True, 4, 2, w, base)
+    buf, offs = fb.merge(w.view(1, N), base_table=torch.tensor([b.data_ptr() for b in base], dtype=torch.int64).to(dev))
+    torch.cuda.synchronize()
+    for p, D in enumerate(sizes):
+        assert torch.equal(outs[p], buf[offs[p]:offs[p] + D])
+    # a mask on another device than the first is refused before any kernel runs (one GPU here: the CPU stands in)
+    with pytest.raises((ValueError, RuntimeError, NotImplementedError)):
+        torch.ops.svdq.mask_combine([masks[0], masks[0].cpu()], "union")
