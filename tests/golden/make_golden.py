@@ -850,8 +850,8 @@ def gen_spectrum_gap():
     refinement trigger must fire on the surplus null direction, not only on the (3e-7, 2e-2) sigma_0 band.  Two
     seeds, centred and not, so that both signs of the first-pass noise are likely to occur."""
     tail = [1.0, 0.8, 0.65, 0.5, 0.4, 0.32, 0.25, 0.2, 0.16, 0.13, 0.1, 0.085, 0.07, 0.06, 0.05, 0.045, 0.04, 0.035, 0.03]
-    specs = [("spectrum_gap_n20a", _structured(5000, 20, tail + [1.0e-4], 108), 0.9999, False),
-             ("spectrum_gap_n20b", _structured_centred(5000, 20, tail[:18] + [1.3e-4], 109, 0.2), 0.9999, True)]
+    specs = [("spectrum_gap_n20a", _structured(5000, 20, tail + [1.0e-4], 108), 0.99, False),
+             ("spectrum_gap_n20b", _structured_centred(5000, 20, tail[:18] + [1.3e-4], 109, 0.2), 0.99, True)]
     _save_spectrum_specs(specs)
 
 # ------------------------------------------------------------------------------- rank KATs
