@@ -69,7 +69,9 @@ def _run_single(vectors: List[torch.Tensor], energy_threshold, max_rank, center,
 def compute_svd(matrix: torch.Tensor, full_matrices: bool = False, use_randomized: bool = False,
                 random_rank: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Reference basis.py:216-249: thin SVD of a tall [D,N] matrix, results on the input's device.
-    Vh is recovered as diag(1/S) U^T A (one N x N product)."""
+    Vh comes out of the eigen-stage itself: the run's coefficient table holds u_i^T a_t = sigma_i v_i[t] in closed
+    form (no centring, fp32 basis: no rounding correction on top), so Vh = diag(1/S) C^T -- N x N numbers already on
+    the host, no second pass over the matrix and no library GEMM."""
     if full_matrices:
         raise ValueError("only the thin SVD (full_matrices=False) is implemented on the HIP path")
     D, N = matrix.shape
@@ -81,8 +83,8 @@ def compute_svd(matrix: torch.Tensor, full_matrices: bool = False, use_randomize
     U_high, U_low, _ = plan.basis_tensors(0, k, r, D)
     U = torch.cat([U_high, U_low], dim=1)
     S = torch.from_numpy(sm.sigma[0, :r].copy()).to(U.device)
-    A = torch.stack([prepare_vector(c, U.device) for c in cols], dim=1)
-    Vh = (U.T @ A) / torch.where(S > 0, S, torch.ones_like(S)).unsqueeze(1)
+    C = torch.from_numpy(sm.coef[0, :N, :r].copy()).to(U.device)       # [task, direction] = sigma_i v_i[t]
+    Vh = C.T / torch.where(S > 0, S, torch.ones_like(S)).unsqueeze(1)
     out_dev = matrix.device
     return U.to(out_dev), S.to(out_dev), Vh.to(out_dev)
 

@@ -213,14 +213,17 @@ class LazyArtifacts(dict):
 def _lazy(name):
     def method(self, *a, **kw):
         self._ensure()
+        for x in a:      # dict.__eq__ / __or__ / update read the OTHER operand through the C dict API, past its wrappers
+            if isinstance(x, LazyArtifacts):
+                x._ensure()
         return getattr(dict, name)(self, *a, **kw)
     method.__name__ = name
     return method
 
 
 for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__eq__", "__ne__", "__setitem__", "__delitem__",
-           "__or__", "__ror__", "keys", "values", "items", "get", "pop", "popitem", "setdefault", "update", "copy",
-           "__bool__" if hasattr(dict, "__bool__") else "__len__"):
+           "__or__", "__ror__", "__ior__", "__reversed__", "keys", "values", "items", "get", "pop", "popitem",
+           "setdefault", "update", "copy", "clear", "__bool__" if hasattr(dict, "__bool__") else "__len__"):
     setattr(LazyArtifacts, _n, _lazy(_n))
 
 

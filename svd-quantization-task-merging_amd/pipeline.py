@@ -458,58 +458,81 @@ class CompressPlan:
 
 # ------------------------------------------------------------------------------------------------
 class _HostViews:
-    """torch views of the host copy of the small artifacts.  Assembling the reference's nested payload dictionaries
-    for a ViT-L model touches ~10^4 scalars and rows, and one torch.tensor() / indexing call per item costs more than
-    the GPU work of the whole model: everything is split with a handful of unbind() calls per field (scalars) or
-    per parameter (rows narrowed to the parameter's n_low / k)."""
+    """torch views of the host copy of the small artifacts, and from them the reference's nested payload dictionaries
+    for EVERY (parameter, task) of the batch, built once and in bulk.  A ViT-L model x 8 tasks is ~16 500 tensor objects
+    (c_high rows, code rows, 0-d scales and zero points) and ~9 500 small dictionaries; one torch.tensor() / indexing
+    call per item costs more than the GPU work of the whole model, so every field is split with ONE unbind per field
+    and distinct row length (parameters grouped by k / n_low: a handful of values), and the dictionaries are zipped
+    together in list comprehensions."""
 
-    def __init__(self, sm: SmallArtifacts):
+    _PKEYS = ("stage", "quantized", "scale", "zero_point", "residual_norm")
+
+    def __init__(self, sm: SmallArtifacts, bits_of, stages: int):
         P, N, S = sm.scale.shape
         self.P, self.N, self.S = P, N, S
-        self.scale = torch.from_numpy(np.ascontiguousarray(sm.scale)).reshape(-1).unbind(0)
-        self.zero_point = torch.from_numpy(np.ascontiguousarray(sm.zero_point)).reshape(-1).unbind(0)
-        self.rnorm = np.ascontiguousarray(sm.residual_norm).reshape(-1).tolist()
-        self.codes = torch.from_numpy(np.ascontiguousarray(sm.codes))          # [P, N, S, N]
-        self.c_high = torch.from_numpy(np.ascontiguousarray(sm.c_high))        # [P, N, N]
-        self.k = sm.k.tolist()
-        self.r = sm.r.tolist()
-        self._per_param = {}
+        k = np.asarray(sm.k, dtype=np.int64)
+        nl = np.asarray(sm.r, dtype=np.int64) - k
+        self.k, self.r = k.tolist(), np.asarray(sm.r).tolist()
+        scale = torch.from_numpy(np.ascontiguousarray(sm.scale)).reshape(-1).unbind(0)
+        zp = torch.from_numpy(np.ascontiguousarray(sm.zero_point)).reshape(-1).unbind(0)
+        rnorm = np.ascontiguousarray(sm.residual_norm).reshape(-1).tolist()
+        c_high = torch.from_numpy(np.ascontiguousarray(sm.c_high))        # [P, N, N]
 
-    def param(self, p: int):
-        """(c_high rows [N] of length k, code rows [N*S] of length n_low) of parameter p, as tuples of views."""
-        got = self._per_param.get(p)
-        if got is None:
-            k, nl = self.k[p], self.r[p] - self.k[p]
-            ch = self.c_high[p, :, :k].unbind(0)
-            cd = self.codes[p, :, :, :nl].reshape(self.N * self.S, nl).unbind(0) if nl > 0 else ()
-            got = (ch, cd)
-            self._per_param[p] = got
-        return got
+        def rows_by_length(a, lengths, per):
+            """a [P, ..., N] (numpy) -> per parameter a tuple of its `per` rows narrowed to lengths[p]: views of one
+            packed copy per distinct length (numpy does the gathering: a torch index op here would wake the intra-op
+            thread pool for a few kilobytes)."""
+            out = [()] * P
+            for ln in np.unique(lengths).tolist():
+                idx = np.nonzero(lengths == ln)[0]
+                if ln <= 0:
+                    continue
+                block = torch.from_numpy(np.ascontiguousarray(a[idx][..., :ln]).reshape(-1, ln)).unbind(0)
+                for j, p in enumerate(idx.tolist()):
+                    out[p] = block[j * per:(j + 1) * per]
+            return out
+
+        self.c_high_rows = rows_by_length(sm.c_high, k, N)       # [p] -> N rows of length k
+        code_rows = rows_by_length(sm.codes, nl, N * S)            # [p] -> N * S rows of length n_low
+        stage_ids = list(range(S)) * N
+        keys = self._PKEYS
+        self.artifacts = []                                        # [p][t] -> compress_single_task layout
+        for p in range(P):
+            n_low, b = int(nl[p]), bits_of(p)
+            shape = torch.Size([max(n_low, 0)])
+            if n_low > 0:
+                lo, hi = p * N * S, (p + 1) * N * S
+                pay = [dict(zip(keys, v)) for v in zip(stage_ids, code_rows[p], scale[lo:hi], zp[lo:hi], rnorm[lo:hi])]
+            else:
+                pay = None
+            ch = self.c_high_rows[p] if k[p] > 0 else [c_high[p, t, :0] for t in range(N)]
+            self.artifacts.append([
+                {"c_high_fp16": ch[t],
+                 "c_low_quant": {"payloads": pay[t * S:(t + 1) * S] if pay is not None else [], "num_bits": b,
+                                 "num_stages": stages, "original_shape": shape, "original_dtype": "torch.float32"}}
+                for t in range(N)])
 
 
-def _views(sm: SmallArtifacts) -> _HostViews:
+def _views(sm: SmallArtifacts, plan=None) -> _HostViews:
     hv = getattr(sm, "_host_views", None)
     if hv is None:
-        hv = _HostViews(sm)
+        hv = _HostViews(sm, plan.bits_of, plan.S)
         sm._host_views = hv
     return hv
 
 
 def quant_payloads(sm: SmallArtifacts, p: int, t: int, nl: int, bits: int, stages: int) -> Dict:
     """RTVQQuantizer.quantize output layout (reference rtvq.py:111-126, payloads rtvq.py:69-75)."""
+    hv = getattr(sm, "_host_views", None)
+    if hv is not None:
+        return hv.artifacts[p][t]["c_low_quant"]
+    P, N, S = sm.scale.shape
     payloads = []
     if nl > 0:
-        hv = _views(sm)
-        cd = hv.param(p)[1]
-        base = (p * hv.N + t) * hv.S
         for s in range(stages):
-            payloads.append({
-                "stage": s,
-                "quantized": cd[t * hv.S + s],
-                "scale": hv.scale[base + s],
-                "zero_point": hv.zero_point[base + s],
-                "residual_norm": hv.rnorm[base + s],
-            })
+            payloads.append({"stage": s, "quantized": torch.from_numpy(sm.codes[p, t, s, :nl].copy()),
+                             "scale": torch.tensor(sm.scale[p, t, s]), "zero_point": torch.tensor(sm.zero_point[p, t, s]),
+                             "residual_norm": float(sm.residual_norm[p, t, s])})
     return {"payloads": payloads, "num_bits": bits, "num_stages": stages,
             "original_shape": torch.Size([nl]), "original_dtype": "torch.float32"}
 
@@ -525,10 +548,9 @@ def basis_dict(plan: CompressPlan, sm: SmallArtifacts, p: int) -> Dict:
 
 
 def task_artifact(plan: CompressPlan, sm: SmallArtifacts, p: int, t: int) -> Dict:
-    """compress_single_task return layout (reference compress.py:53-56); CPU tensors."""
-    hv = _views(sm)
-    return {"c_high_fp16": hv.param(p)[0][t],
-            "c_low_quant": quant_payloads(sm, p, t, hv.r[p] - hv.k[p], plan.bits_of(p), plan.S)}
+    """compress_single_task return layout (reference compress.py:53-56); CPU tensors.  The dictionaries of the whole
+    batch are assembled in bulk on the first call (_HostViews) and handed out from there."""
+    return _views(sm, plan).artifacts[p][t]
 
 
 class BatchResult:

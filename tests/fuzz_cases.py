@@ -68,8 +68,15 @@ def oracle_case(sq, orc, dev, seed: int, c: int):
                         msgs.append(f"recon mse {mse:.2e} task {t} (reference noise {ref_noise:.1e})")
                         break
                     coarse = True
-        if coarse and eo2 > 2.5 ** 2 * er2 + 1e-12:
-            msgs.append(f"rms recon error vs original {eo2 ** 0.5:.3e} vs reference {er2 ** 0.5:.3e}")
+        # How far two valid bases can differ in this criterion depends on the freedom they have: inside a cluster of
+        # near-equal singular values among the quantized directions ANY rotation is a valid basis (the structured
+        # generator's noise tail is such a cluster) -- observed 0.74x .. 1.92x over 60 configurations, bound 2.5x; with
+        # every quantized direction separated by a clear gap only the signs are free: bound 1.5x.
+        low = S_ref[k:r][real[k:r]]
+        clustered = low.size >= 2 and bool(np.any(np.abs(np.diff(low)) < 0.05 * low[:-1]))
+        bound = 2.5 if clustered else 1.5
+        if coarse and eo2 > bound ** 2 * er2 + 1e-12:
+            msgs.append(f"rms recon error vs original {eo2 ** 0.5:.3e} vs reference {er2 ** 0.5:.3e} (bound {bound}x)")
     plan.close()
     return desc, msgs
 
@@ -147,6 +154,27 @@ def modes_case(sq, dev, seed: int, c: int):
     m = _same(r4, gb)
     if m:
         msgs.append("gather_from_base: " + m)
-    for pl in (r2, fb, r3, ga, r4, gb):
+    extra = []
+    if N <= 16:
+        # the mask walk (no index lists): against the compacted run, and straight from checkpoints against ingest + walk
+        mtab = torch.tensor([x.data_ptr() for x in ms._i["mb"]], dtype=torch.int64).to(dev)
+        wk = CompressPlan(sizes, N, **kw)
+        us = ms.unit_starts(wk, ct2, mask_table=mtab)
+        wk.run_masked(wk.pointer_table(deltas), mtab, us, ct2)
+        torch.cuda.synchronize()
+        m = _same(r3, wk)
+        if m:
+            msgs.append("walk: " + m)
+        w4 = CompressPlan(sizes, N, **kw)
+        w4.run_masked(w4.pointer_table(ingv), mtab, ms.unit_starts(w4, ct2, mask_table=mtab), ct2)
+        wb = CompressPlan(sizes, N, **kw)
+        wb.run_masked_from_base(wb.pointer_table(fts), torch.tensor([b.data_ptr() for b in base], dtype=torch.int64).to(dev),
+                                mtab, ms.unit_starts(wb, ct2, mask_table=mtab), ct2)
+        torch.cuda.synchronize()
+        m = _same(w4, wb)
+        if m:
+            msgs.append("walk_from_base: " + m)
+        extra = [wk, w4, wb]
+    for pl in [r2, fb, r3, ga, r4, gb] + extra:
         pl.close()
     return desc, msgs
