@@ -629,6 +629,14 @@ def main():
             torch.cuda.empty_cache()
             wl.placement_error = f"{type(e).__name__}: {str(e)[:160]}"
     elapsed, total_scalars, kms = wl.timed(dist, args.steps, args.warmup)
+    # N > 1: every rank's own stage times and share of the rows, so that the first real multi-GPU run shows imbalance
+    per_rank = None
+    if dist is not None:
+        mine_info = {"rank": rank, "tensors": len(rows), "sum_rows": int(sum(rows)),
+                     "kernels_ms": [round(x, 4) if x == x else None for x in kms]}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine_info)
+        per_rank = gathered
     plan = wl.plan
     sm = plan.fetch_small()
     k_mean = float(sm.k.mean())
@@ -718,6 +726,8 @@ def main():
                                     if ceilings else None),
             "ms_per_step_incl_small_d2h": round(d2h_ms, 4) if d2h_ms is not None else None,
         }
+        if per_rank is not None:
+            out["per_rank"] = {"stages": ["k_gram", "k_reduce+k_eig", "k_basis_project", "k_reduce+k_coeff"], "ranks": per_rank}
         if untuned is not None:
             out["untuned"] = untuned
         if bgather is not None:

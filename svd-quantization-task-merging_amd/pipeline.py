@@ -468,6 +468,16 @@ class _HostViews:
     _PKEYS = ("stage", "quantized", "scale", "zero_point", "residual_norm")
 
     def __init__(self, sm: SmallArtifacts, bits_of, stages: int):
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()      # ~26 000 container objects in one go: keep the cyclic collector from re-walking them all
+        try:
+            self._build(sm, bits_of, stages)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _build(self, sm: SmallArtifacts, bits_of, stages: int):
         P, N, S = sm.scale.shape
         self.P, self.N, self.S = P, N, S
         k = np.asarray(sm.k, dtype=np.int64)
