@@ -1038,6 +1038,27 @@ UNROLL_N(SVDQ_UNROLL_BP)
         for (int jj = 0; jj < NPAIR; ++jj) {
             f32x4 err[NB][2];  // E = fp16(U) - U for the two sub-tiles of this pair
             f32x4 xb[NB][2];
+            // every LDS operand of the pair is read before its first MFMA (one round trip per pair; read one by one in
+            // front of each MFMA the chain ds_read -> wait -> mfma leaves a wave idle for most of the sub-tile, which the
+            // two or three waves per SIMD of N > 8 cannot cover: N = 20 pass 2 7.99 -> 7.7 ms)
+            float xa[2][KS][PACK];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int h = 0; h < PACK; ++h) xa[s2][s][h] = X[(4 * s + g) * XS + TROWS * (2 * jj + s2) + 16 * h + c];
+            if constexpr (OUT16) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        xb[nb][s2] = *reinterpret_cast<const f32x4 *>(xb_ptr[nb] + TROWS * (2 * jj + s2));
+                        if (!xb_ok[nb]) xb[nb][s2] = zero4();
+                    }
+            }
+            // (alternating the two sub-tiles' accumulation chains -- a dependent MFMA then issues 64 cycles after its
+            // predecessor instead of right behind it -- measured nothing: 7.31 / 7.36 ms at N = 20, 5.39 / 5.53 at N = 16)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int j = 2 * jj + s2;
@@ -1047,14 +1068,11 @@ UNROLL_N(SVDQ_UNROLL_BP)
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     if constexpr (PACK == 2) {
-                        const float a0 = X[(4 * s + g) * XS + 32 * j + c];
-                        const float a1 = X[(4 * s + g) * XS + 32 * j + 16 + c];
-                        u[0] = mfma4(a0, w[s][0], u[0]);
-                        u[0] = mfma4(a1, whi[s], u[0]);
+                        u[0] = mfma4(xa[s2][s][0], w[s][0], u[0]);
+                        u[0] = mfma4(xa[s2][s][1], whi[s], u[0]);
                     } else {
-                        const float a = X[(4 * s + g) * XS + 16 * j + c];
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) u[nb] = mfma4(a, w[s][nb], u[nb]);
+                        for (int nb = 0; nb < NB; ++nb) u[nb] = mfma4(xa[s2][s][0], w[s][nb], u[nb]);
                     }
                 }
                 // row 0 of the completion column (see k_eig)
@@ -1078,10 +1096,6 @@ UNROLL_N(SVDQ_UNROLL_BP)
                         } else {
                             dst[e * colstride[nb]] = u[nb][e];
                         }
-                    }
-                    if constexpr (OUT16) {
-                        xb[nb][s2] = *reinterpret_cast<const f32x4 *>(xb_ptr[nb] + TROWS * j);
-                        if (!xb_ok[nb]) xb[nb][s2] = zero4();
                     }
                 }
             }
@@ -1473,12 +1487,17 @@ UNROLL_N(SVDQ_UNROLL_BP2)
         for (int jj = 0; jj < 8; ++jj) {
             f32x4 err[2];
             f32x4 xb[2][2];
+            float xa[2][KS];      // the pair's A operands, read before the first MFMA (see k_basis_project)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) xa[s2][s] = X[(4 * s + g) * XS + 16 * (2 * jj + s2) + c];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int j = 2 * jj + s2;
                 f32x4 u = zero4();
 #pragma unroll
-                for (int s = 0; s < KS; ++s) u = mfma4(X[(4 * s + g) * XS + 16 * j + c], w[s], u);
+                for (int s = 0; s < KS; ++s) u = mfma4(xa[s2][s], w[s], u);
                 if (j == 0 && rb == 0 && g == 0 && icol == nullcol) u[0] += spike;  // completion column, row 0
                 out_t *dst = colbase + (16 * j + 4 * g) * colstride;
 #pragma unroll
@@ -1722,6 +1741,11 @@ __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
         }
     }
     wave_sync();   // W1 is in LDS
+    float w1r[G1][NTP];      // B operands of the 4x4x1 chains: this lane's column of every group, constant over the unit
+#pragma unroll
+    for (int q = 0; q < G1; ++q)
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) w1r[q][t] = W1[t * N1 + 4 * q + j4];
 
     for (int64_t rb = r_begin; rb < r_end; rb += HB) {
         // ---- centre (same association as pass 1 at N > 16: two halves of the tasks), park the strip, write the mean
@@ -1778,12 +1802,26 @@ __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
         for (int jj = 0; jj < HB / 32; ++jj) {
             f32x4 err[2];
             f32x4 xb[2][2];
+            // the A operands of BOTH sub-tiles of the pair are read before the first MFMA: one LDS round trip per pair
+            // instead of one per MFMA (the chain ds_read -> wait -> mfma, ten times, left the wave idle for most of it)
+            float xa[2][KS];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) xa[s2][s] = X[(4 * s + g) * XH + 16 * (2 * jj + s2) + c];
+            if constexpr (OUT16) {      // ... and the projection's B operands with them
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        xb[nb][s2] = *reinterpret_cast<const f32x4 *>(xbrow[nb] + 16 * (2 * jj + s2));
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int j = 2 * jj + s2;
                 f32x4 u = zero4();
 #pragma unroll
-                for (int s = 0; s < KS; ++s) u = mfma4(X[(4 * s + g) * XH + 16 * j + c], w0[s], u);
+                for (int s = 0; s < KS; ++s) u = mfma4(xa[s2][s], w0[s], u);
                 if (j == 0 && rb == 0 && g == 0 && c == nullcol) u[0] += spike;   // completion column, row 0
                 out_t *dst = cb0 + (16 * j + 4 * g) * cs0;
 #pragma unroll
@@ -1796,10 +1834,6 @@ __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
                         dst[e * cs0] = u[e];
                     }
                 }
-                if constexpr (OUT16) {
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) xb[nb][s2] = *reinterpret_cast<const f32x4 *>(xbrow[nb] + 16 * j);
-                }
             }
             if constexpr (OUT16) {
                 const bf16x8 ea = pack_bf16(err[0], err[1]);
@@ -1810,11 +1844,20 @@ __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
         // ---- columns 16..: two 64-row groups of sixteen 4x4 blocks
 #pragma unroll
         for (int grp = 0; grp < HB / 64; ++grp) {
+            float xr[NTP];      // this lane's row of every task: read once per group, before the MFMA chains
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) xr[t] = X[t * XH + 64 * grp + lane];
+            f32x4 xq[KS];       // A operands of the 4x4x4 correction: four rows of four tasks per task group
+            if constexpr (OUT16) {
+#pragma unroll
+                for (int tg = 0; tg < KS; ++tg)
+                    xq[tg] = *reinterpret_cast<const f32x4 *>(X + (4 * tg + j4) * XH + 64 * grp + 4 * b4);
+            }
 #pragma unroll
             for (int q = 0; q < G1; ++q) {
                 f32x4 u = zero4();
 #pragma unroll
-                for (int t = 0; t < NTP; ++t) u = mfma_4x4x1(X[t * XH + 64 * grp + lane], W1[t * N1 + 4 * q + j4], u);
+                for (int t = 0; t < NTP; ++t) u = mfma_4x4x1(xr[t], w1r[q][t], u);
                 if (grp == 0 && rb == 0 && b4 == 0 && 16 + 4 * q + j4 == nullcol) u[0] += spike;
                 out_t *dst = cb1[q] + (64 * grp + 4 * b4) * cs1[q];
                 f32x4 er;
@@ -1831,10 +1874,8 @@ __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
                 if constexpr (OUT16) {
                     const s16x4 eb = pack_bf16x4(er);
 #pragma unroll
-                    for (int tg = 0; tg < KS; ++tg) {
-                        const f32x4 xa = *reinterpret_cast<const f32x4 *>(X + (4 * tg + j4) * XH + 64 * grp + 4 * b4);
-                        cacc1[q][tg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(pack_bf16x4(xa), eb, cacc1[q][tg], 0, 0, 0);
-                    }
+                    for (int tg = 0; tg < KS; ++tg)
+                        cacc1[q][tg] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(pack_bf16x4(xq[tg]), eb, cacc1[q][tg], 0, 0, 0);
                 }
             }
         }
