@@ -29,14 +29,17 @@ void svdq_set_error(const char *fmt, ...) {
 extern "C" int svdq_abi_version(void) { return SVDQ_ABI_VERSION; }
 extern "C" const char *svdq_last_error(void) { return g_err; }
 
-static int32_t auto_unit_rows(int64_t D) {
+static int32_t auto_unit_rows(int64_t D, int32_t n_tasks) {
     // Measured on MI355X (bench.py --unit-rows sweeps, tools/shard_one.py): for a whole ViT-L-14 / ViT-B-32 model
     // 4096..8192-row units are equal within noise (smaller ones multiply the fp64 partial slots the two small kernels
     // must reduce), but one rank's share of the 8-GPU run has only ~4 700 units of 8192 rows for 5 120 resident waves --
     // a single partial wave, 0.765 ms against 0.699 ms with 4096-row units.  The unit size is a function of the
     // tensor alone (never of what else is in the plan), so a tensor's artifacts are the same bits in any batch and on
     // any number of GPUs.  Small tensors get >= 4 units when they have the rows for it, never less than 4 blocks each.
-    int64_t ur = 4096;
+    // N > 16: a unit's partial matrices are N x N doubles (3.2 KB at N = 20) and the two reduction kernels read all of
+    // them -- 237 MB per launch for ViT-L-14 x 20 with 4096-row units, bandwidth-bound; 8192-row units halve that
+    // (0.39 -> 0.31 ms for the four small launches, the streaming passes unchanged).  Still a function of (tensor, N) alone.
+    int64_t ur = n_tasks > 16 ? 8192 : 4096;
     if (D < 4 * ur) ur = svdq_align_up((D + 3) / 4, SVDQ_BLK_ROWS);
     if (ur < 4 * SVDQ_BLK_ROWS) ur = 4 * SVDQ_BLK_ROWS;
     return (int32_t)ur;
@@ -92,7 +95,7 @@ extern "C" int svdq_plan_create(svdq_plan **out, int32_t n_tasks, int32_t n_para
     int64_t n_units = 0, basis_bytes = 0, mean_floats = 0;
     for (int p = 0; p < n_params; ++p) {
         const int64_t D = rows[p];
-        const int32_t ur = cfg->unit_rows > 0 ? cfg->unit_rows : auto_unit_rows(D);
+        const int32_t ur = cfg->unit_rows > 0 ? cfg->unit_rows : auto_unit_rows(D, n_tasks);
         const int64_t cnt = (D + ur - 1) / ur;
         SvdqParam &pd = pl->h_params[p];
         pd.rows = D;
@@ -116,7 +119,7 @@ extern "C" int svdq_plan_create(svdq_plan **out, int32_t n_tasks, int32_t n_para
     pl->h_units = (SvdqUnit *)calloc(n_units, sizeof(SvdqUnit));
     for (int p = 0; p < n_params; ++p) {
         const int64_t D = rows[p];
-        const int32_t ur = cfg->unit_rows > 0 ? cfg->unit_rows : auto_unit_rows(D);
+        const int32_t ur = cfg->unit_rows > 0 ? cfg->unit_rows : auto_unit_rows(D, n_tasks);
         const SvdqParam &pd = pl->h_params[p];
         for (int32_t i = 0; i < pd.unit_count; ++i) {
             SvdqUnit &u = pl->h_units[pd.unit_begin + i];
