@@ -46,7 +46,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+# profiled HBM bytes per launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this round's
+# binary, tools/r03_pmc_traffic.sh): (model, tasks, masked) -> file
+TRAFFIC_FILES = {("ViT-L-14", 8, False): os.path.join("profiles", "r03_pmc_traffic.json"),
+                 ("ViT-L-14", 20, False): os.path.join("profiles", "r03_n20_pmc_traffic.json"),
+                 ("ViT-B-16", 8, True): os.path.join("profiles", "r03_masked_vitb16_pmc_traffic.json")}
 
 
 def parse():
@@ -146,14 +150,13 @@ def spawn_ranks(n: int) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ helpers
-def profiled_traffic(kernel: str, model: str, n_tasks: int):
+def profiled_traffic(kernel: str, model: str, n_tasks: int, masked: bool = False):
     """HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
     this same command on this round's binary, FETCH_SIZE doubled as the gfx950 guide prescribes).  Counters cannot be
     read from inside the run, so this is a PROFILED figure, labelled with its source; None for other workloads."""
-    files = {("ViT-L-14", 8): TRAFFIC_FILE, ("ViT-L-14", 20): TRAFFIC_FILE.replace("r02_", "r02_n20_")}
-    if (model, n_tasks) not in files:
+    if (model, n_tasks, masked) not in TRAFFIC_FILES:
         return None, None
-    tf = files[(model, n_tasks)]
+    tf = TRAFFIC_FILES[(model, n_tasks, masked)]
     try:
         d = json.load(open(os.path.join(ROOT, tf)))
         for name, v in d["kernels"].items():
@@ -683,7 +686,8 @@ def main():
         # whole path, deltas counted ONCE; over all ranks (strong: one model; weak: one per rank)
         path_bytes = (total_scalars / N) * (6 * N + 4)
         two_pass_bytes = (total_scalars / N) * (10 * N + 4)
-        traffic, traffic_src = profiled_traffic("k_basis_project", args.model, N) if world == 1 else (None, None)
+        traffic, traffic_src = (profiled_traffic("k_basis_project", args.model, N, args.masks != "none")
+                                if world == 1 and args.from_base == "off" else (None, None))
         out = {
             "metric": "MParams/s SVD+RTVQ compressed (Params = N_tasks * sum D_p task-vector scalars)",
             "value": round(value, 1), "unit": "MParams/s", "n_gpus": world, "steps": args.steps,
@@ -693,7 +697,11 @@ def main():
                                    f"sum D = {int(sumD)} on rank 0, energy {args.energy}, center, fp16 bases, "
                                    f"{args.bits}-bit x {args.stages}-stage RTVQ",
                        "tensors_rank0": len(rows), "tasks": N, "mean_rank_k": round(k_mean, 2), "units": n_units,
-                       "schedule": "6 kernels: gram, reduce, eig, basis_project, reduce, coeff (+ a 4-byte memset)",
+                       "schedule": ("6 kernels: gram, reduce, eig, basis_project, reduce, coeff (+ a 4-byte memset)" +
+                                    ("; before them mask vote + tile scan + unit starts (3 kernels), the two passes in "
+                                     "mask-walk mode" if args.masks != "none" and getattr(wl, "walk", False) else
+                                     ("; before them mask vote + tile scan + index lists (3 kernels), the two passes "
+                                      "in gather mode" if args.masks != "none" else ""))),
                        "gram": "fp32 products" if (args.gram32 or N > 16) else "fp64 MFMA (exact products)",
                        "from_base": args.from_base,
                        "output_placement": (f"CompressPlan.tune_placement, once before the timed region: "
