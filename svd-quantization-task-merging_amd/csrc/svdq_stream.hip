@@ -398,11 +398,11 @@ __device__ __forceinline__ void walk_zero_tail(float *X, int fill, int lane) {
 // whole unit), which resolves singular values down to ~1e-6 sigma_0 like the reference's LAPACK path; the fp32 form
 // (fp32 sums inside a 256-row block) only reaches ~1e-3..1e-4 sigma_0.  Pass 1 is HBM-bound for N <= 16, so the fp64
 // form is the default there; N > 16 would become MFMA-bound and keeps fp32 products.
-template <int NTP, int MODE = 0, bool F64 = false>
+template <int NTP, int MODE = 0, bool F64 = false, bool FULL = false>
 __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *__restrict__ params,
                                           const SvdqUnit *__restrict__ units,
                                           const float *const *__restrict__ ptrs,
-                                          const int64_t *__restrict__ rows_dev, int NT, int center,
+                                          const int64_t *__restrict__ rows_dev, int NT_arg, int center,
                                           double *__restrict__ gram_part,
                                           const void *const *__restrict__ aux = nullptr,
                                           const int32_t *__restrict__ only = nullptr,
@@ -411,6 +411,7 @@ __device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *_
     constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0, WALK = (MODE & 4) != 0;
     static_assert(!(GATHER && WALK), "index lists and the mask walk are alternatives");
     static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
+    const int NT = FULL ? NTP : NT_arg;      // FULL: the plan has exactly NTP tasks, the "task t is real" tests fold away
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
     // N = 17..20: of the 2x2-blocked Gram only AA is a full 16 x 16 tile; AB is 16 x 4 and BB 4 x 4.  A 16x16x4 MFMA per
@@ -841,7 +842,7 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
 #ifndef SVDQ_GRAM64_WAVES16
 #define SVDQ_GRAM64_WAVES16 3
 #endif
-template <int NTP, int MODE, bool F64>
+template <int NTP, int MODE, bool F64, bool FULL>
 __global__ __launch_bounds__(64, (F64 && (MODE == 0 || MODE == 4) && NTP <= 16) ? (NTP <= 8 ? SVDQ_GRAM64_WAVES8 : SVDQ_GRAM64_WAVES16) : 1) void k_gram(const SvdqParam *__restrict__ params,
                                              const SvdqUnit *__restrict__ units,
                                              const float *const *__restrict__ ptrs,
@@ -852,8 +853,8 @@ __global__ __launch_bounds__(64, (F64 && (MODE == 0 || MODE == 4) && NTP <= 16) 
                                              const void *const *__restrict__ aux2, int order,
                                              const int64_t *__restrict__ ustart) {
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
-    gram_unit<NTP, MODE, F64>(X, unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, order), params, units, ptrs,
-                              rows_dev, NT, center, gram_part, aux, only, aux2, ustart);
+    gram_unit<NTP, MODE, F64, FULL>(X, unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, order), params, units, ptrs,
+                                    rows_dev, NT, center, gram_part, aux, only, aux2, ustart);
 }
 
 // ------------------------------------------------------------------------------------ pass 2
@@ -901,17 +902,19 @@ __device__ __forceinline__ bf16x8 pack_bf16(const f32x4 &lo, const f32x4 &hi) {
 // 2^-12 term is 2^-21 of c, below the fp32 accumulation noise of the direct product.
 // One work unit of pass 2 by ONE wavefront.  X: NTP*XS floats, OUT: SVDQ_BLK_ROWS*NTP + 16 elements of
 // wave-private LDS.
-template <int NTP, bool OUT16, int MODE = 0>
+// FULL: the plan has exactly NTP tasks -- every "task t is real" test folds away (see k_basis_project_q)
+template <int NTP, bool OUT16, int MODE = 0, bool FULL = false>
 __device__ __forceinline__ void bp_unit(
     float *X, typename OutT<OUT16>::type *OUT, int uidx, const SvdqParam *__restrict__ params,
     const SvdqUnit *__restrict__ units, const float *const *__restrict__ ptrs,
-    const int64_t *__restrict__ rows_dev, int NT, int center, const float *__restrict__ Wtab,
+    const int64_t *__restrict__ rows_dev, int NT_arg, int center, const float *__restrict__ Wtab,
     const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev, uint8_t *__restrict__ basis,
     float *__restrict__ meanbuf, double *__restrict__ cpart, const void *const *__restrict__ aux = nullptr,
     const void *const *__restrict__ aux2 = nullptr, const int64_t *__restrict__ ustart = nullptr) {
     constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0, WALK = (MODE & 4) != 0;
     static_assert(!(GATHER && WALK), "index lists and the mask walk are alternatives");
     static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
+    const int NT = FULL ? NTP : NT_arg;
     constexpr int PACK = (NTP <= 8) ? 2 : 1;
     constexpr int NB = (NTP + 15) / 16;
     constexpr int KS = NTP / 4;
@@ -1262,7 +1265,7 @@ UNROLL_N(SVDQ_UNROLL_BP)
     }
 }
 
-template <int NTP, bool OUT16, int MODE>
+template <int NTP, bool OUT16, int MODE, bool FULL>
 __global__ __launch_bounds__(64) void k_basis_project(
     const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
     const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
@@ -1273,8 +1276,8 @@ __global__ __launch_bounds__(64) void k_basis_project(
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
     __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];  // +16: dump slot for idle lanes
     const int uidx = unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, reverse);
-    bp_unit<NTP, OUT16, MODE>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis,
-                              meanbuf, cpart, aux, aux2, ustart);
+    bp_unit<NTP, OUT16, MODE, FULL>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis,
+                                    meanbuf, cpart, aux, aux2, ustart);
 }
 
 // ------------------------------------------------------------------------------------ N > 16: two waves
@@ -1586,14 +1589,19 @@ __device__ __forceinline__ s16x4 pack_bf16x4(const f32x4 &x) {
 #ifndef SVDQ_Q_WAVES
 #define SVDQ_Q_WAVES 1
 #endif
-template <int NTP, bool OUT16, int MODE>
+// FULL: the plan has exactly NTP tasks (N = 20, N = 24).  With N a run-time value every "task t is real" test is a
+// lane mask the compiler keeps in a scalar-register pair across the loop -- twenty of them, which is what pushed the
+// twenty task pointers out of the scalar registers (a v_readlane pair + a 64-bit vector add per load) and put a
+// v_cndmask on every value of the centring (round 3: ~200 of ~1 000 wave instructions per half block).
+template <int NTP, bool OUT16, int MODE, bool FULL>
 __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
     const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
-    const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT, int center,
+    const float *const *__restrict__ ptrs, const int64_t *__restrict__ rows_dev, int NT_arg, int center,
     const float *__restrict__ Wtab, const int32_t *__restrict__ k_dev, const int32_t *__restrict__ r_dev,
     uint8_t *__restrict__ basis, float *__restrict__ meanbuf, double *__restrict__ cpart, int unit0, int reverse,
     const void *const *__restrict__ aux, const void *const *__restrict__ aux2) {
     static_assert(NTP == 20 || NTP == 24, "the 4x4-block variant covers 16 < N <= 24");
+    const int NT = FULL ? NTP : NT_arg;
     constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0;
     using out_t = typename OutT<OUT16>::type;
     constexpr int KS = NTP / 4;    // k-steps of the 16x16x4 chain = task groups of the 4x4x4 correction
@@ -1708,12 +1716,14 @@ __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
             }
         } else {
             const int64_t rr = rb + 2 * lane;
-            const uint32_t off = (uint32_t)(rb - r_begin) + 2u * (uint32_t)lane;   // rows past the unit's first row
+            // BYTE offset past the unit's first row, 32 bits: scalar base + 32-bit vector offset is an addressing mode
+            // of global_load (a 64-bit element offset makes every load a 64-bit vector add first)
+            const uint32_t boff = ((uint32_t)(rb - r_begin) + 2u * (uint32_t)lane) * 4u;
             if (rb + HB <= D) {
 #pragma unroll
                 for (int t = 0; t < NTP; ++t) {
                     gfloat *bt = (SVDQ_Q_PTR_RELOAD ? (gfloat *)ptab[(t < NT ? t : NT - 1) + hop] : bp[t]) + r_begin;
-                    v[t] = *reinterpret_cast<gf32x2 *>(bt + off);
+                    v[t] = *reinterpret_cast<gf32x2 *>(reinterpret_cast<const __attribute__((address_space(1))) char *>(bt) + boff);
                 }
                 if constexpr (SUB) vb = *reinterpret_cast<gf32x2 *>(gbase + rr);
             } else {
@@ -1923,9 +1933,20 @@ static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *r
                          const int32_t *only, const int64_t *ustart, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
     auto ai = (const void *const *)idx, ab = (const void *const *)base;
-#define SVDQ_LAUNCH_GRAM(M, F)                                                                                       \
-    hipLaunchKernelGGL((k_gram<NTP, M, F>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, rows_dev, \
+#define SVDQ_LAUNCH_GRAM_(M, F, FULL_)                                                                                     \
+    hipLaunchKernelGGL((k_gram<NTP, M, F, FULL_>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, rows_dev, \
                        pl->n_tasks, center, gram_part, unit0, ai, only, ab, pl->cfg.reserved & 4, ustart)
+    // the plain and the mask-walk mode have a variant for plans with exactly NTP tasks
+#define SVDQ_LAUNCH_GRAM(M, F)                                                                                       \
+    do {                                                                                                             \
+        if constexpr ((M) == 0 || (M) == 4) {                                                                        \
+            if (pl->n_tasks == NTP) {                                                                                \
+                SVDQ_LAUNCH_GRAM_(M, F, true);                                                                       \
+                break;                                                                                               \
+            }                                                                                                        \
+        }                                                                                                            \
+        SVDQ_LAUNCH_GRAM_(M, F, false);                                                                              \
+    } while (0)
     const int mode = ustart ? (4 | (base ? 2 : 0)) : ((idx ? 1 : 0) | (base ? 2 : 0));
     if constexpr (NTP <= 16) {
         if (mode & 4) {      // walk mode exists for the one-wave kernels (N <= 16), always with the default Gram
@@ -1958,6 +1979,7 @@ static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *r
         }
     }
 #undef SVDQ_LAUNCH_GRAM
+#undef SVDQ_LAUNCH_GRAM_
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
@@ -1985,14 +2007,16 @@ static int launch_bp_mode(const svdq_plan *pl, const float *const *pp, const int
     auto ai = (const void *const *)idx, ab = (const void *const *)base;
     if (ustart) {
         if constexpr (NTP <= 16) {
-            if (base)
-                hipLaunchKernelGGL((k_basis_project<NTP, F16, 6>), dim3(nunits), dim3(64), 0, st, pl->d_params,
-                                   pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,
-                                   cpart, unit0, reverse, ai, ab, ustart);
-            else
-                hipLaunchKernelGGL((k_basis_project<NTP, F16, 4>), dim3(nunits), dim3(64), 0, st, pl->d_params,
-                                   pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,
-                                   cpart, unit0, reverse, ai, ab, ustart);
+#define SVDQ_LAUNCH_BPW(M, FULL_)                                                                                     \
+    hipLaunchKernelGGL((k_basis_project<NTP, F16, M, FULL_>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, \
+                       pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean, cpart, unit0, reverse, \
+                       ai, ab, ustart)
+            if (pl->n_tasks == NTP) {
+                if (base) SVDQ_LAUNCH_BPW(6, true); else SVDQ_LAUNCH_BPW(4, true);
+            } else {
+                if (base) SVDQ_LAUNCH_BPW(6, false); else SVDQ_LAUNCH_BPW(4, false);
+            }
+#undef SVDQ_LAUNCH_BPW
             return SVDQ_OK;
         }
         svdq_set_error("the mask-walk mode covers N <= 16 tasks (got %d): use the index lists (svdq_compress_gather)",
@@ -2003,9 +2027,14 @@ static int launch_bp_mode(const svdq_plan *pl, const float *const *pp, const int
     do {                                                                                                              \
         if constexpr (NTP == 20) {   /* N = 21..24: measured slower than the two-wave kernel (11.9 against 10.0 ms) */ \
             if (!(pl->cfg.reserved & 8)) {   /* bit 3: the two-wave kernel instead (A/B) */                           \
-                hipLaunchKernelGGL((k_basis_project_q<NTP, F16, M>), dim3(nunits), dim3(64), 0, st, pl->d_params,     \
-                                   pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis,    \
-                                   mean, cpart, unit0, reverse, ai, ab);                                              \
+                if (pl->n_tasks == NTP)                                                                               \
+                    hipLaunchKernelGGL((k_basis_project_q<NTP, F16, M, true>), dim3(nunits), dim3(64), 0, st,         \
+                                       pl->d_params, pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, \
+                                       r_dev, basis, mean, cpart, unit0, reverse, ai, ab);                            \
+                else                                                                                                  \
+                    hipLaunchKernelGGL((k_basis_project_q<NTP, F16, M, false>), dim3(nunits), dim3(64), 0, st,        \
+                                       pl->d_params, pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, \
+                                       r_dev, basis, mean, cpart, unit0, reverse, ai, ab);                            \
                 break;                                                                                                \
             }                                                                                                         \
         }                                                                                                             \
@@ -2013,8 +2042,12 @@ static int launch_bp_mode(const svdq_plan *pl, const float *const *pp, const int
             hipLaunchKernelGGL((k_basis_project2<NTP, F16, M>), dim3(nunits), dim3(128), 0, st, pl->d_params,         \
                                pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
                                cpart, unit0, reverse, ai, ab);                                                        \
+        else if (pl->n_tasks == NTP)                                                                                  \
+            hipLaunchKernelGGL((k_basis_project<NTP, F16, M, true>), dim3(nunits), dim3(64), 0, st, pl->d_params,     \
+                               pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
+                               cpart, unit0, reverse, ai, ab, (const int64_t *)nullptr);                              \
         else                                                                                                          \
-            hipLaunchKernelGGL((k_basis_project<NTP, F16, M>), dim3(nunits), dim3(64), 0, st, pl->d_params,           \
+            hipLaunchKernelGGL((k_basis_project<NTP, F16, M, false>), dim3(nunits), dim3(64), 0, st, pl->d_params,    \
                                pl->d_units, pp, rows_dev, pl->n_tasks, pl->cfg.center, W, k_dev, r_dev, basis, mean,  \
                                cpart, unit0, reverse, ai, ab, (const int64_t *)nullptr);                              \
     } while (0)
