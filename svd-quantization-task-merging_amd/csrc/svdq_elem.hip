@@ -1302,7 +1302,7 @@ extern "C" int svdq_maskset_combine_packed_indices(const svdq_maskset *ms, const
 }
 
 // ------------------------------------------------------------------------------------ walk mode: unit starts
-// The mask-walk mode of the streaming passes (svdq_compress_masked, svdq_stream.hip "walk mode") needs, for every work
+// The mask-walk mode of the streaming passes (svdq_compress_masked, svdq_stream.h "walk mode") needs, for every work
 // unit of the plan, the SOURCE position of the unit's first row -- the element of rank unit.row0 among the selected
 // (or, for the noise region, the cleared) elements of its mask.  One wavefront per unit: a 64-ary search over the
 // exclusive tile offsets of the scan, then one pass over the 2048 mask bytes of the tile that holds the element.

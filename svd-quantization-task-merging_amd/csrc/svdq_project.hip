@@ -1,861 +1,6 @@
-// svdq_stream.hip -- the two HBM-streaming passes of the SVD-Hybrid compressor (gfx950 / CDNA4).
-//
-//   k_gram          pass 1: G = Tc^T Tc          (reference basis.py:63-113 + the reduction half of
-//                                                  torch.linalg.svd, basis.py:216-249)
-//   k_basis_project pass 2: U = Tc W -> fp16, mean, c = fp16(U)^T Tc
-//                                                 (basis.py:363-364, cli.py:354-361, compress.py:6-21,35-40)
-//
-// Both walk the same 256-row blocks.  One wavefront (= one 64-thread workgroup, so LDS is
-// wave-private and no cross-wave barrier exists) owns a unit of consecutive blocks:
-//
-//   global --16 B/lane, 1 KiB contiguous per task per instruction--> VGPR (next block prefetched)
-//          --row mean over tasks, subtract--> LDS  X[task][row]  (centred, zero past the end)
-//          --ds_read in the two MFMA operand layouts--> v_mfma_f32_16x16x4_f32
-//
-// MFMA operand layouts (16x16x4 f32: lane l supplies A[l&15][l>>4] and B[l>>4][l&15],
-// holds D[4*(l>>4)+reg][l&15]):
-//   "task on slot, row on k"  value X[task l&15][row 4*(l>>4)+e]   one ds_read_b128 = 4 MFMA steps
-//        Gram:        D[m][n] += X[m][row] * X[n][row]   (A and B are the SAME register)
-//        projection:  B operand; A operand is the rounded U tile straight out of the U-MFMA
-//                     accumulator (its D layout is exactly "U column on slot, row on k").
-//   "row on slot, task on k"  value X[task 4s+(l>>4)][row l&15]    ds_read_b32 per k-step s
-//        U = Tc W:    A operand; B operand W[4s+(l>>4)][l&15] lives in registers.
-//   Row-set packing (N <= 8): slots 0-7 carry tasks for one 16-row set, slots 8-15 the same tasks
-//   for the next 16 rows; the two diagonal 8x8 blocks of D are two independent partial sums.
-//
-// Accumulation: fp32 inside a block (64 MFMA k-steps), fp64 across blocks and units.
-
-#include "svdq_common.h"
-#include <hip/hip_fp16.h>
-
-#define XS SVDQ_XS
-#ifndef SVDQ_EXP_ULOW_SHIFT
-#define SVDQ_EXP_ULOW_SHIFT 0   // experiment builds only (tools/placement_probe7.py): U_low written this many bytes further
-#endif
-#ifndef SVDQ_UNROLL_BP
-#define SVDQ_UNROLL_BP 8
-#endif
-#ifndef SVDQ_UNROLL_BP2
-#define SVDQ_UNROLL_BP2 4  // sub-tile-pair loop of the two-wave pass 2 (N > 16)
-#endif
-#ifndef SVDQ_UNROLL_GRAM
-#define SVDQ_UNROLL_GRAM 8
-#endif
-#ifndef SVDQ_UNROLL_GRAM_P1
-#define SVDQ_UNROLL_GRAM_P1 16  // sub-tile loop of the unpacked (N > 8) Gram variants
-#endif
-#ifndef SVDQ_NT_LOADS
-#define SVDQ_NT_LOADS 0
-#endif
-#ifndef SVDQ_NT_STORES
-#define SVDQ_NT_STORES 0
-#endif
-#ifndef SVDQ_PREFETCH2
-#define SVDQ_PREFETCH2 0  // 1: two register sets, loads two blocks ahead (measured: no gain, fewer waves)
-#endif
-#define PRAGMA_(x) _Pragma(#x)
-#define UNROLL_N(n) PRAGMA_(unroll n)
-
-// Which work unit a workgroup takes.  Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8),
-// and consecutive units are consecutive row ranges of one tensor.  order bit 2 ("XCD-chunked"): XCD x walks ONE
-// contiguous eighth of the unit list, so the address window its L2 and its translation caches see at any time is an
-// eighth of what the interleaved order gives.  bit 0: reversed unit order (measurement).
-__device__ __forceinline__ int unit_of_block(int b, int n, int order) {
-    int u = b;
-    if (order & 4) {
-        const int q = n >> 3, rem = n & 7, x = b & 7;
-        u = x * q + (x < rem ? x : rem) + (b >> 3);
-    }
-    return (order & 1) ? n - 1 - u : u;
-}
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// One wavefront per workgroup: LDS operations of a wave execute in order, so phases only need the
-// COMPILER kept from moving LDS accesses across the boundary.  __syncthreads() would also emit
-// s_waitcnt vmcnt(0), draining this wave's global stores and prefetched loads once per block.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-// v_mfma_f64_16x16x4_f64: operands as the f32 form (one value per lane: A[l&15][l>>4], B[l>>4][l&15]); the
-// accumulator layout differs: lane l holds D[(l>>4) + 4*reg][l&15].  A product of two fp32 values is exact in
-// fp64, so a Gram accumulated this way carries only the ~1e-16 rounding of the running sums.
-__device__ __forceinline__ f64x4 mfma4d(double a, double b, f64x4 c) {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
-
-// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 blocks, D_b[i][j] += A_b[i] B_b[j]; lane l belongs to block l / 4,
-// supplies A_b[l % 4] and B_b[l % 4] and holds D_b[register][l % 4] (tools/probe/mfma_layout.hip); 8 cycles.
-__device__ __forceinline__ f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ f32x4 zero4() {
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    return z;
-}
-
-// Task-delta pointers come out of a device table, so the compiler only knows them as generic
-// ("flat") pointers; flat loads count on BOTH vmcnt and lgkmcnt, which would make every LDS wait
-// also drain the next block's prefetch.  Cast them to the global address space explicitly.
-typedef const __attribute__((address_space(1))) float gfloat;
-typedef const __attribute__((address_space(1))) f32x4 gf32x4;
-
-// Issue the 16-B loads of one 256-row block: lane l takes rows rb+4l..rb+4l+3 of every task.
-// Full blocks take the unconditional path (no per-load branch, all loads in flight together);
-// only the last block of a parameter takes the guarded one.
-template <int NTP>
-__device__ __forceinline__ void load_block(f32x4 (&v)[NTP], gfloat *(&bp)[NTP], int64_t rb,
-                                           int64_t D, int lane) {
-    const int64_t r = rb + 4 * lane;
-    if (rb + SVDQ_BLK_ROWS <= D) {
-#pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-#if SVDQ_NT_LOADS
-            v[t] = __builtin_nontemporal_load(reinterpret_cast<gf32x4 *>(bp[t] + r));
-#else
-            v[t] = *reinterpret_cast<gf32x4 *>(bp[t] + r);
-#endif
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-            f32x4 o = zero4();
-            if (r < D) o.x = bp[t][r];
-            if (r + 1 < D) o.y = bp[t][r + 1];
-            if (r + 2 < D) o.z = bp[t][r + 2];
-            if (r + 3 < D) o.w = bp[t][r + 3];
-            v[t] = o;
-        }
-    }
-}
-
-// Gather mode (masked parameters without a compaction pass): the kernels walk the COMPACTED row space and
-// fetch row j of every task from source element idx[j] (ascending positions of the set mask bits, built
-// once per mask by svdq_maskset_indices).  Outputs stay exactly as in the contiguous mode.  Indices are
-// loaded one block ahead of the data they address, so the data loads never wait for them.
-typedef const __attribute__((address_space(1))) int32_t gint;
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(1))) i32x4 gi32x4;
-
-// In gather mode lane l owns rows l, 64+l, 128+l, 192+l of a block (not 4l..4l+3): the four dword loads of a
-// task then each read 64 CONSECUTIVE compacted rows -- a nearly contiguous 256-byte run of the source -- instead
-// of every fourth row of a 1 KiB span, which would make each instruction touch the same 16 cache lines.
-__device__ __forceinline__ i32x4 load_idx(gint *idx, int64_t rb, int64_t D, int lane) {
-    const int64_t r = rb + lane;
-    i32x4 o = {-1, -1, -1, -1};
-    if (rb + SVDQ_BLK_ROWS <= D) {
-        o.x = idx[r];
-        o.y = idx[r + 64];
-        o.z = idx[r + 128];
-        o.w = idx[r + 192];
-    } else {
-        if (r < D) o.x = idx[r];
-        if (r + 64 < D) o.y = idx[r + 64];
-        if (r + 128 < D) o.z = idx[r + 128];
-        if (r + 192 < D) o.w = idx[r + 192];
-    }
-    return o;
-}
-
-// "Minus base" mode (svdq_compress_from_base): the task tensors are FINE-TUNED weights and the delta
-// finetuned - base is formed in registers, so the task vectors are never written to or read back from HBM.
-__device__ __forceinline__ f32x4 load_base(gfloat *b, int64_t rb, int64_t D, int lane) {
-    const int64_t r = rb + 4 * lane;
-    if (rb + SVDQ_BLK_ROWS <= D) return *reinterpret_cast<gf32x4 *>(b + r);
-    f32x4 o = zero4();
-    if (r < D) o.x = b[r];
-    if (r + 1 < D) o.y = b[r + 1];
-    if (r + 2 < D) o.z = b[r + 2];
-    if (r + 3 < D) o.w = b[r + 3];
-    return o;
-}
-
-// base rows of a gathered block (minus-base mode combined with gather mode): same indices as the task rows
-__device__ __forceinline__ f32x4 load_base_gather(gfloat *b, const i32x4 &ix, bool full) {
-    f32x4 o = zero4();
-    if (full) {
-        o.x = b[ix.x];
-        o.y = b[ix.y];
-        o.z = b[ix.z];
-        o.w = b[ix.w];
-    } else {
-        if (ix.x >= 0) o.x = b[ix.x];
-        if (ix.y >= 0) o.y = b[ix.y];
-        if (ix.z >= 0) o.z = b[ix.z];
-        if (ix.w >= 0) o.w = b[ix.w];
-    }
-    return o;
-}
-
-template <int NTP>
-__device__ __forceinline__ void load_block_gather(f32x4 (&v)[NTP], gfloat *(&bp)[NTP], const i32x4 &ix, bool full) {
-    if (full) {
-#pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-            f32x4 o;
-            o.x = bp[t][ix.x];
-            o.y = bp[t][ix.y];
-            o.z = bp[t][ix.z];
-            o.w = bp[t][ix.w];
-            v[t] = o;
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-            f32x4 o = zero4();
-            if (ix.x >= 0) o.x = bp[t][ix.x];
-            if (ix.y >= 0) o.y = bp[t][ix.y];
-            if (ix.z >= 0) o.z = bp[t][ix.z];
-            if (ix.w >= 0) o.w = bp[t][ix.w];
-            v[t] = o;
-        }
-    }
-}
-
-// Row mean over the NT real tasks (sum in task order, then one fp32 divide: basis.py:109).  Component-wise over the
-// lane's four rows, whichever rows those are.
-template <int NTP>
-__device__ __forceinline__ f32x4 row_mean(const f32x4 (&v)[NTP], int NT, int center) {
-    f32x4 s = zero4();
-    if constexpr (NTP > 16) {
-        // same association as the two-wave pass 2 (each wave sums half of the tasks, then h0 + h1): pass 1 and
-        // pass 2 must centre with the same mean, bit for bit
-        f32x4 h[2];
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            h[w] = zero4();
-#pragma unroll
-            for (int i = 0; i < NTP / 2; ++i) {
-                const int t = w * (NTP / 2) + i;
-                h[w] += (t < NT) ? v[t] : zero4();
-            }
-        }
-        s = h[0] + h[1];
-    } else {
-#pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-            f32x4 x = (t < NT) ? v[t] : zero4();
-            s += x;
-        }
-    }
-    f32x4 mean = zero4();
-    if (center) {
-        const float n = (float)NT;
-        mean.x = s.x / n;
-        mean.y = s.y / n;
-        mean.z = s.z / n;
-        mean.w = s.w / n;
-    }
-    return mean;
-}
-
-// Subtract the row mean (basis.py:111) and park the centred strip in LDS.  Padded tasks are stored as 0.
-// STRIDED (gather mode): component e of a lane's vector is row 64 e + lane, not 4 lane + e.
-template <int NTP, bool STRIDED = false>
-__device__ __forceinline__ f32x4 center_store(const f32x4 (&v)[NTP], int NT, int center, float *X, int lane) {
-    const f32x4 mean = row_mean<NTP>(v, NT, center);
-#pragma unroll
-    for (int t = 0; t < NTP; ++t) {
-        f32x4 xc = (t < NT) ? (v[t] - mean) : zero4();
-        if constexpr (STRIDED) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) X[t * XS + 64 * e + lane] = xc[e];
-        } else {
-            *reinterpret_cast<f32x4 *>(X + t * XS + 4 * lane) = xc;
-        }
-    }
-    return mean;
-}
-
-// ------------------------------------------------------------------------------------ walk mode (masked parameters)
-// MODE bit 2.  Masked parameters WITHOUT index lists (reference mask_loader.py:651-709 applied inside the passes):
-// a unit still owns a run of 256-row blocks of the COMPACTED row space -- so every artifact bit is where the
-// compacted / gather modes put it -- but it reaches them by walking the SOURCE tensor from the position of its first
-// selected element (ustart[unit], found once per mask by svdq_maskset_*_starts from the tile scan):
-//   * chunk = 256 consecutive source rows; lane l owns rows src + 64 e + l (e = 0..3), so every dword load of a task
-//     reads 256 contiguous bytes and every mask load 64 contiguous bytes -- 4 N + 1 bytes per source row and pass,
-//     nothing per selected row (the index lists cost 4 bytes per selected row and pass on top of the rows themselves);
-//   * the four ballots of "row selected" give every selected row its rank in the chunk (s_bcnt / v_mbcnt, no scan
-//     through LDS); rank + rows already in the strip = its row in the current block;
-//   * centred values are scattered into the strip with ds_write_b32 -- consecutive lanes hold consecutive selected
-//     rows, so the writes are conflict-free; rows that overflow the block wait in registers until the block has been
-//     consumed (phase B below) and then open the next one.
-// Loads past the unit's last source row (the next unit's start, or the end of the tensor) are masked off, so
-// neighbouring units do not fetch each other's rows beyond the sector they share.
-typedef const __attribute__((address_space(1))) uint8_t gbyte;
-#define SVDQ_WALK_INV (1ll << 62)      // ustart[u] bit 62: select the CLEARED mask elements (the noise region)
-
-__device__ __forceinline__ int lanes_below(unsigned long long bal) {
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-}
-
-struct WalkSel {
-    bool sel[4];   // this lane's row e is selected
-    int pos[4];    // its row in the strip, counted from the start of the current block (may be >= 256)
-    int total;     // rows in the strip once the chunk is in (wave-uniform)
-};
-
-// the chunk's data: row src + 64 e + lane of every task (and of the base tensor, minus-base mode) + the mask bytes
-template <int NTP, bool SUB>
-__device__ __forceinline__ void walk_load(f32x4 (&v)[NTP], f32x4 &vb, unsigned (&mk)[4], gfloat *(&bp)[NTP],
-                                          gfloat *gbase, gbyte *gmask, int64_t src, int64_t src_end, int lane) {
-    const int64_t r = src + lane;
-    if (src + SVDQ_BLK_ROWS <= src_end) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mk[e] = gmask[r + 64 * e];
-#pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-            f32x4 o;
-            o.x = bp[t][r];
-            o.y = bp[t][r + 64];
-            o.z = bp[t][r + 128];
-            o.w = bp[t][r + 192];
-            v[t] = o;
-        }
-        if constexpr (SUB) {
-            vb.x = gbase[r];
-            vb.y = gbase[r + 64];
-            vb.z = gbase[r + 128];
-            vb.w = gbase[r + 192];
-        }
-    } else {
-        bool in[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            in[e] = r + 64 * e < src_end;
-            mk[e] = in[e] ? (unsigned)gmask[r + 64 * e] : 0x100u;   // 0x100: past the end, selected by neither polarity
-        }
-#pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-            f32x4 o = zero4();
-            if (in[0]) o.x = bp[t][r];
-            if (in[1]) o.y = bp[t][r + 64];
-            if (in[2]) o.z = bp[t][r + 128];
-            if (in[3]) o.w = bp[t][r + 192];
-            v[t] = o;
-        }
-        if constexpr (SUB) {
-            vb = zero4();
-            if (in[0]) vb.x = gbase[r];
-            if (in[1]) vb.y = gbase[r + 64];
-            if (in[2]) vb.z = gbase[r + 128];
-            if (in[3]) vb.w = gbase[r + 192];
-        }
-    }
-}
-
-// ranks of the chunk's selected rows (ascending source position = e-major, lane-minor)
-__device__ __forceinline__ WalkSel walk_select(const unsigned (&mk)[4], int inv, int fill) {
-    WalkSel w;
-    int base = fill;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        w.sel[e] = inv ? (mk[e] == 0u) : (mk[e] != 0u && mk[e] != 0x100u);
-        const unsigned long long bal = __ballot(w.sel[e]);
-        w.pos[e] = base + lanes_below(bal);
-        base += (int)__popcll(bal);
-    }
-    w.total = base;
-    return w;
-}
-
-// strip rows [lo, lo + 256) of the chunk: phase A (lo = 0) completes the current block, phase B (lo = 256) opens the next
-template <int NTP>
-__device__ __forceinline__ void walk_scatter(float *X, const f32x4 (&xc)[NTP], const WalkSel &w, int lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int q = w.pos[e] - lo;
-        if (w.sel[e] && (unsigned)q < (unsigned)SVDQ_BLK_ROWS) {
-#pragma unroll
-            for (int t = 0; t < NTP; ++t) X[t * XS + q] = xc[t][e];
-        }
-    }
-}
-
-// rows [fill, 256) of the strip <- 0 (the last, partial block of a parameter)
-template <int NTP>
-__device__ __forceinline__ void walk_zero_tail(float *X, int fill, int lane) {
-    for (int q = fill + lane; q < SVDQ_BLK_ROWS; q += 64) {
-#pragma unroll
-        for (int t = 0; t < NTP; ++t) X[t * XS + q] = 0.f;
-    }
-}
-
-// ------------------------------------------------------------------------------------ pass 1
-// One work unit of pass 1 (a run of 256-row blocks of one parameter) by ONE wavefront.
-// X: NTP*XS floats of wave-private LDS.
-// MODE bit 0: gather through an index list (aux[p] = int32 list); bit 1: the task tensors are fine-tuned weights and a
-// base tensor is subtracted in registers (aux2[p] = base).  0 = contiguous task vectors, 3 = both.
-// F64: the products are accumulated by v_mfma_f64_16x16x4_f64 (exact fp32 x fp32 products, fp64 running sums over the
-// whole unit), which resolves singular values down to ~1e-6 sigma_0 like the reference's LAPACK path; the fp32 form
-// (fp32 sums inside a 256-row block) only reaches ~1e-3..1e-4 sigma_0.  Pass 1 is HBM-bound for N <= 16, so the fp64
-// form is the default there; N > 16 would become MFMA-bound and keeps fp32 products.
-template <int NTP, int MODE = 0, bool F64 = false, bool FULL = false>
-__device__ __forceinline__ void gram_unit(float *X, int uidx, const SvdqParam *__restrict__ params,
-                                          const SvdqUnit *__restrict__ units,
-                                          const float *const *__restrict__ ptrs,
-                                          const int64_t *__restrict__ rows_dev, int NT_arg, int center,
-                                          double *__restrict__ gram_part,
-                                          const void *const *__restrict__ aux = nullptr,
-                                          const int32_t *__restrict__ only = nullptr,
-                                          const void *const *__restrict__ aux2 = nullptr,
-                                          const int64_t *__restrict__ ustart = nullptr) {
-    constexpr bool GATHER = (MODE & 1) != 0, SUB = (MODE & 2) != 0, WALK = (MODE & 4) != 0;
-    static_assert(!(GATHER && WALK), "index lists and the mask walk are alternatives");
-    static_assert(!(MODE != 0 && SVDQ_PREFETCH2), "gather / minus-base support the one-block-ahead pipeline only");
-    const int NT = FULL ? NTP : NT_arg;      // FULL: the plan has exactly NTP tasks, the "task t is real" tests fold away
-    constexpr int PACK = (NTP <= 8) ? 2 : 1;
-    constexpr int NB = (NTP + 15) / 16;
-    // N = 17..20: of the 2x2-blocked Gram only AA is a full 16 x 16 tile; AB is 16 x 4 and BB 4 x 4.  A 16x16x4 MFMA per
-    // k-step for each of them wastes 3/4 and 15/16 of the matrix pipe, and pass 1 at N = 20 is MFMA-issue-bound
-    // (SQ_WAIT_INST_ANY 69 %, MFMA busy 58 %).  They are taken by v_mfma_f32_4x4x1_16b_f32 instead -- sixteen 4x4 outer
-    // products per instruction, 8 cycles:  AB: block (mg, rg) = tasks 4mg..4mg+3 x tasks 16..19 on row 4rg + e of the
-    // sub-tile (four instructions per 16 rows);  BB: block b = row b of the sub-tile (one instruction per 16 rows).
-    // 2 688 matrix-pipe cycles per 256-row block instead of 4 096 plus the vector-ALU corner.
-    constexpr bool VBB = (NTP == 20) && !F64;
-    constexpr int NACC = (NB == 1 || VBB) ? 1 : 3;  // AA | AA, AB, BB
-    // N = 5..8 with exact products: the 8 x 8 Gram is four 4 x 4 tiles, which is exactly one v_mfma_f64_4x4x4_4b_f64
-    // (four blocks, K = 4 rows, 16 cycles) -- the 16x16x4 form spends 64 cycles on two useful 8 x 8 corners of a 16 x 16
-    // tile.  Layout probed on the device (tools/probe/mfma_f64_layout.hip): lane l = (k = l >> 4, b = (l >> 2) & 3,
-    // x = l & 3) supplies A_b[x][k] and B_b[k][x] and holds D_b[i = l >> 4][j = l & 3]; block b = tile (b >> 1, b & 1).
-    // The lane's k selects rows 4k..4k+3 of a 16-row sub-tile (one 16-byte LDS read per operand), the four
-    // instructions of a sub-tile take one of them each.  1 024 instead of 2 048 matrix-pipe cycles per block.
-    // The same instruction serves every N <= 16 (T = NTP / 4 tile rows): only the T (T + 1) / 2 tiles on or above the
-    // diagonal are computed, four per instruction -- T = 1: the four blocks take four different 16-row groups of the
-    // one tile (summed at the end); T = 2: all four tiles in one instruction; T = 3: six tiles in two instructions;
-    // (T = 4: ten tiles in three, was measured SLOWER than the 16x16x4 form -- 4.62 against 3.58 ms at ViT-L-14 x 16:
-    // every 4x4x4 instruction needs two converted operands per lane, eight times the v_cvt_f64_f32 work per output --
-    // so N = 13..16 stays on 16x16x4.)  Matrix-pipe cycles per four rows: 4 / 16 / 32 against 64 for the 16x16x4 form,
-    // which at N <= 4 made pass 1 matrix-bound (1.52 -> 0.52 ms for the 2.4 GB of ViT-L-14 x 2; N = 4: 1.58 -> 0.83;
-    // N = 12: 3.21 -> 2.98).
-    constexpr bool Q64 = F64 && (NTP <= 12);
-    constexpr int TQ = NTP / 4;
-    constexpr int NTILE = TQ * (TQ + 1) / 2;
-    constexpr int NSET = (TQ == 2) ? 1 : (NTILE + 3) / 4;   // T = 2 keeps its redundant (1,0) tile: one instruction anyway
-
-    const int lane = threadIdx.x & 63;
-    const SvdqUnit ud = units[uidx];
-    const int p = ud.param;
-    if (only && !only[p]) return;  // refinement pass (N > 16): only the parameters the eigen-stage flagged
-    const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
-    const int64_t r_begin = ud.row0;
-    int64_t r_end = r_begin + ud.nrows;
-    if (r_end > D) r_end = D;
-
-    gfloat *bp[NTP];
-#pragma unroll
-    for (int t = 0; t < NTP; ++t) bp[t] = (gfloat *)ptrs[(size_t)p * NT + (t < NT ? t : NT - 1)];
-
-    const int c = lane & 15, g = lane >> 4;
-    double accd[NACC][4];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) accd[i][e] = 0.0;
-
-#ifndef SVDQ_GRAM64_CHAINS
-#define SVDQ_GRAM64_CHAINS 1
-#endif
-    constexpr int QC = (NB == 1) ? SVDQ_GRAM64_CHAINS : 1;  // F64: independent accumulation chains per block
-    f64x4 accq[NACC * QC];
-#pragma unroll
-    for (int i = 0; i < NACC * QC; ++i) accq[i] = f64x4{0.0, 0.0, 0.0, 0.0};
-
-    double q64[Q64 ? NSET : 1];   // Q64: this lane's Gram entries (one per instruction of a step), over the whole unit
-#ifndef SVDQ_Q64_CHAINS
-#define SVDQ_Q64_CHAINS 2   // independent accumulation chains per entry (even / odd k-steps), added at the end of the unit
-#endif
-    double q64b[(Q64 && SVDQ_Q64_CHAINS == 2) ? NSET : 1];
-#pragma unroll
-    for (int i = 0; i < (Q64 ? NSET : 1); ++i) q64[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < ((Q64 && SVDQ_Q64_CHAINS == 2) ? NSET : 1); ++i) q64b[i] = 0.0;
-    // tile (ti <= tj) number q in row-major order of the upper triangle
-    auto tile_of = [](int q, int &ti, int &tj) {
-        ti = 0;
-        int rowlen = TQ;
-        while (q >= rowlen) {
-            q -= rowlen;
-            --rowlen;
-            ++ti;
-        }
-        tj = ti + q;
-    };
-    double qd[2][4];  // VBB: AB and BB block partials of the 4x4x1 chains (fp32 inside a block, fp64 across)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) qd[i][e] = 0.0;
-    const int b4 = lane >> 2, i4 = lane & 3, mg4 = b4 & 3, rg4 = b4 >> 2;
-
-    // The loads of the next block (or next two, SVDQ_PREFETCH2) are in flight while a block is computed.
-    constexpr int AHEAD = SVDQ_PREFETCH2 ? 2 : 1;
-    f32x4 v0[NTP];
-    gint *gidx = nullptr;
-    i32x4 ixn = {-1, -1, -1, -1};  // indices of the block after the one whose data is in flight
-    gfloat *gbase = nullptr;
-    f32x4 vb = zero4();  // base rows of the block whose fine-tuned rows sit in v
-    if constexpr (SUB) gbase = (gfloat *)aux2[p];
-    if constexpr (WALK) {
-        // loads are issued by the walk loop below
-    } else if constexpr (GATHER) {
-        gidx = (gint *)aux[p];
-        if (r_begin < r_end) {
-            const i32x4 ix0 = load_idx(gidx, r_begin, D, lane);
-            load_block_gather<NTP>(v0, bp, ix0, r_begin + SVDQ_BLK_ROWS <= D);
-            if constexpr (SUB) vb = load_base_gather(gbase, ix0, r_begin + SVDQ_BLK_ROWS <= D);
-            if (r_begin + SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, r_begin + SVDQ_BLK_ROWS, D, lane);
-        }
-    } else {
-        if (r_begin < r_end) load_block<NTP>(v0, bp, r_begin, D, lane);
-        if constexpr (SUB) {
-            if (r_begin < r_end) vb = load_base(gbase, r_begin, D, lane);
-        }
-    }
-#if SVDQ_PREFETCH2
-    f32x4 v1[NTP];
-    if (r_begin + SVDQ_BLK_ROWS < r_end) load_block<NTP>(v1, bp, r_begin + SVDQ_BLK_ROWS, D, lane);
-#endif
-
-    // the MFMA phase over the strip of one block (ends with the barrier that frees the strip)
-    auto compute = [&]() {
-        f32x4 acc[NACC];
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = zero4();
-        f32x4 qab = zero4(), qbb = zero4();
-
-        if constexpr (Q64) {
-            const int kq = lane >> 4, bq = (lane >> 2) & 3, xq = lane & 3;
-            if constexpr (TQ == 1) {
-                // one tile: block b takes rows 16b..16b+15 of every 64-row group; A and B are the same value
-                const float *pa = X + xq * XS + 16 * bq + 4 * kq;
-UNROLL_N(4)
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 a = *reinterpret_cast<const f32x4 *>(pa + 64 * j);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const double ad = (double)a[e];
-                        if (SVDQ_Q64_CHAINS == 2 && (e & 1))
-                            q64b[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, ad, q64b[0], 0, 0, 0);
-                        else
-                            q64[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ad, ad, q64[0], 0, 0, 0);
-                    }
-                }
-            } else {
-                const float *pa[NSET], *pb[NSET];
-#pragma unroll
-                for (int st = 0; st < NSET; ++st) {
-                    int ti, tj;
-                    if constexpr (TQ == 2) {
-                        ti = bq >> 1;
-                        tj = bq & 1;
-                    } else {
-                        const int q = 4 * st + bq;
-                        tile_of(q < NTILE ? q : NTILE - 1, ti, tj);   // spare blocks repeat the last tile, unused
-                    }
-                    pa[st] = X + (4 * ti + xq) * XS + 4 * kq;
-                    pb[st] = X + (4 * tj + xq) * XS + 4 * kq;
-                }
-UNROLL_N(SVDQ_UNROLL_GRAM)
-                for (int j = 0; j < 16; ++j) {
-#pragma unroll
-                    for (int st = 0; st < NSET; ++st) {
-                        const f32x4 a = *reinterpret_cast<const f32x4 *>(pa[st] + 16 * j);
-                        const f32x4 b = *reinterpret_cast<const f32x4 *>(pb[st] + 16 * j);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (SVDQ_Q64_CHAINS == 2 && (e & 1))
-                                q64b[st] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a[e], (double)b[e], q64b[st], 0, 0, 0);
-                            else
-                                q64[st] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a[e], (double)b[e], q64[st], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        } else if constexpr (PACK == 2) {
-            const int t = c & 7;
-            const bool valid = t < NTP;
-            const float *xr = X + (valid ? t : 0) * XS + 16 * (c >> 3) + 4 * g;
-UNROLL_N(SVDQ_UNROLL_GRAM)
-            for (int j = 0; j < 8; ++j) {
-                f32x4 a = *reinterpret_cast<const f32x4 *>(xr + 32 * j);
-                if (!valid) a = zero4();
-                if constexpr (F64) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const double ad = (double)a[e];
-                        accq[e % QC] = mfma4d(ad, ad, accq[e % QC]);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[0] = mfma4(a[e], a[e], acc[0]);
-                }
-            }
-        } else {
-            const bool v0ok = c < NTP;
-            const bool v1ok = (NB == 2) && (16 + c < NTP);
-            const float *x0 = X + (v0ok ? c : 0) * XS + 4 * g;
-            const float *x1 = X + (v1ok ? 16 + c : 0) * XS + 4 * g;
-UNROLL_N(SVDQ_UNROLL_GRAM_P1)
-            for (int j = 0; j < 16; ++j) {
-                f32x4 a0 = *reinterpret_cast<const f32x4 *>(x0 + 16 * j);
-                if (!v0ok) a0 = zero4();
-                if constexpr (F64 && NB == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const double ad = (double)a0[e];
-                        accq[e % QC] = mfma4d(ad, ad, accq[e % QC]);
-                    }
-                } else if constexpr (F64) {
-                    f32x4 a1 = *reinterpret_cast<const f32x4 *>(x1 + 16 * j);
-                    if (!v1ok) a1 = zero4();
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const double d0 = (double)a0[e], d1 = (double)a1[e];
-                        accq[0] = mfma4d(d0, d0, accq[0]);
-                        accq[1] = mfma4d(d0, d1, accq[1]);
-                        accq[2] = mfma4d(d1, d1, accq[2]);
-                    }
-                } else if constexpr (NB == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[0] = mfma4(a0[e], a0[e], acc[0]);
-                } else if constexpr (VBB) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[0] = mfma4(a0[e], a0[e], acc[0]);
-                    const f32x4 xa = *reinterpret_cast<const f32x4 *>(X + (4 * mg4 + i4) * XS + 16 * j + 4 * rg4);
-                    const f32x4 xq = *reinterpret_cast<const f32x4 *>(X + (16 + i4) * XS + 16 * j + 4 * rg4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) qab = mfma_4x4x1(xa[e], xq[e], qab);
-                    const float xr = X[(16 + i4) * XS + 16 * j + b4];
-                    qbb = mfma_4x4x1(xr, xr, qbb);
-                } else {
-                    f32x4 a1 = *reinterpret_cast<const f32x4 *>(x1 + 16 * j);
-                    if (!v1ok) a1 = zero4();
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[0] = mfma4(a0[e], a0[e], acc[0]);
-                        acc[1] = mfma4(a0[e], a1[e], acc[1]);
-                        acc[2] = mfma4(a1[e], a1[e], acc[2]);
-                    }
-                }
-            }
-        }
-        if constexpr (!F64) {
-#pragma unroll
-            for (int i = 0; i < NACC; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) accd[i][e] += (double)acc[i][e];
-            if constexpr (VBB) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    qd[0][e] += (double)qab[e];
-                    qd[1][e] += (double)qbb[e];
-                }
-            }
-        }
-        wave_sync();
-    };
-
-    if constexpr (WALK) {
-        // walk the source rows from this unit's first selected element (see "walk mode" above)
-        gbyte *gmask = (gbyte *)aux[p];
-        const int64_t Dsrc = params[p].rows;
-        const int64_t us = ustart[uidx];
-        const int inv = (us & SVDQ_WALK_INV) ? 1 : 0;
-        int64_t src = us & (SVDQ_WALK_INV - 1);
-        int64_t src_end = Dsrc;      // where the next unit's rows begin
-        if (uidx + 1 < params[p].unit_begin + params[p].unit_count) src_end = ustart[uidx + 1] & (SVDQ_WALK_INV - 1);
-        if (src_end > Dsrc) src_end = Dsrc;
-        const int need = (r_begin < r_end) ? (int)(r_end - r_begin) : 0;
-        int produced = 0, fill = 0;
-        unsigned mk[4];
-        bool have = need > 0 && src < src_end;
-        if (have) walk_load<NTP, SUB>(v0, vb, mk, bp, gbase, gmask, src, src_end, lane);
-        bool more = need > 0;
-        while (more) {
-            const int fill0 = fill;
-            WalkSel w;
-            w.total = SVDQ_BLK_ROWS;      // no chunk left: flush the partial block
-            if (have) {
-                w = walk_select(mk, inv, fill0);
-                if constexpr (SUB) {
-#pragma unroll
-                    for (int t = 0; t < NTP; ++t) v0[t] = v0[t] - vb;
-                }
-                const f32x4 mean = row_mean<NTP>(v0, NT, center);
-#pragma unroll
-                for (int t = 0; t < NTP; ++t) v0[t] = (t < NT) ? (v0[t] - mean) : zero4();
-                walk_scatter<NTP>(X, v0, w, 0);
-            } else {
-                walk_zero_tail<NTP>(X, fill0, lane);
-            }
-            if (w.total >= SVDQ_BLK_ROWS) {
-                wave_sync();
-                compute();
-                if (have) walk_scatter<NTP>(X, v0, w, SVDQ_BLK_ROWS);
-                fill = have ? w.total - SVDQ_BLK_ROWS : 0;
-            } else {
-                fill = w.total;
-            }
-            if (have) {
-                produced += w.total - fill0;
-                src += SVDQ_BLK_ROWS;
-            }
-            have = have && produced < need && src < src_end;
-            if (have) walk_load<NTP, SUB>(v0, vb, mk, bp, gbase, gmask, src, src_end, lane);
-            more = have || fill > 0;
-        }
-    } else {
-        auto do_block = [&](f32x4 (&v)[NTP], int64_t rb) {
-            if constexpr (SUB) {
-#pragma unroll
-                for (int t = 0; t < NTP; ++t) v[t] = v[t] - vb;
-            }
-            center_store<NTP, GATHER>(v, NT, center, X, lane);
-            wave_sync();
-            if (rb + AHEAD * SVDQ_BLK_ROWS < r_end) {
-                if constexpr (GATHER) {
-                    load_block_gather<NTP>(v, bp, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
-                    if constexpr (SUB) vb = load_base_gather(gbase, ixn, rb + 2 * SVDQ_BLK_ROWS <= D);
-                    if (rb + 2 * SVDQ_BLK_ROWS < r_end) ixn = load_idx(gidx, rb + 2 * SVDQ_BLK_ROWS, D, lane);
-                } else {
-                    load_block<NTP>(v, bp, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
-                    if constexpr (SUB) vb = load_base(gbase, rb + AHEAD * SVDQ_BLK_ROWS, D, lane);
-                }
-            }
-            compute();
-        };
-        for (int64_t rb = r_begin; rb < r_end; rb += AHEAD * SVDQ_BLK_ROWS) {
-            do_block(v0, rb);
-#if SVDQ_PREFETCH2
-            if (rb + SVDQ_BLK_ROWS < r_end) do_block(v1, rb + SVDQ_BLK_ROWS);
-#endif
-        }
-    }
-    if constexpr (F64) {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                double t = accq[i * QC][e];
-#pragma unroll
-                for (int q = 1; q < QC; ++q) t += accq[i * QC + q][e];
-                accd[i][e] = t;
-            }
-    }
-
-    // One fp64 partial per slot, dense [NT][NT].  Lane (c,g) holds D[4g+e][c] (fp32 MFMA) or D[g+4e][c] (fp64 MFMA).
-    const int NN = NT * NT;
-    if constexpr (Q64 && SVDQ_Q64_CHAINS == 2) {
-#pragma unroll
-        for (int st = 0; st < NSET; ++st) q64[st] += q64b[st];
-    }
-    if constexpr (Q64) {   // everything in the unit's first slot; N <= 8 has a second slot per unit: zeros
-        const int i = lane >> 4, bq = (lane >> 2) & 3, jq = lane & 3;
-        double *dst = gram_part + (size_t)uidx * PACK * NN;
-        if constexpr (TQ == 1) {
-            double x = q64[0];
-            x += __shfl_xor(x, 4);
-            x += __shfl_xor(x, 8);
-            if (bq == 0 && i < NT && jq < NT) {
-                dst[i * NT + jq] = x;
-                dst[NN + i * NT + jq] = 0.0;
-            }
-        } else if constexpr (TQ == 2) {
-            const int m = 4 * (bq >> 1) + i, n = 4 * (bq & 1) + jq;
-            if (m < NT && n < NT) {
-                dst[m * NT + n] = q64[0];
-                dst[NN + m * NT + n] = 0.0;
-            }
-        } else {
-#pragma unroll
-            for (int st = 0; st < NSET; ++st) {
-                const int q = 4 * st + bq;
-                if (q < NTILE) {
-                    int ti, tj;
-                    tile_of(q, ti, tj);
-                    const int m = 4 * ti + i, n = 4 * tj + jq;
-                    if (m < NT && n < NT) {
-                        dst[m * NT + n] = q64[st];
-                        if (ti != tj) dst[n * NT + m] = q64[st];
-                    }
-                }
-            }
-        }
-    } else if constexpr (PACK == 2) {
-        const int rs = c >> 3, n = c & 7;
-        double *dst = gram_part + ((size_t)uidx * 2 + rs) * NN;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = F64 ? g + 4 * e : 4 * g + e;
-            if ((m >> 3) == rs && (m & 7) < NT && n < NT) dst[(m & 7) * NT + n] = accd[0][e];
-        }
-    } else {
-        double *dst = gram_part + (size_t)uidx * NN;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = F64 ? g + 4 * e : 4 * g + e;
-            if (m < NT && c < NT) dst[m * NT + c] = accd[0][e];
-            if constexpr (NB == 2 && !VBB) {
-                if (m < NT && 16 + c < NT) {
-                    dst[m * NT + 16 + c] = accd[1][e];
-                    dst[(16 + c) * NT + m] = accd[1][e];
-                }
-                if (16 + m < NT && 16 + c < NT) dst[(16 + m) * NT + 16 + c] = accd[2][e];
-            }
-        }
-        if constexpr (VBB) {   // block partials meet in fixed-order shuffles
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // AB: lane (block (mg, rg), j) register e = [task 4mg + e][task 16 + j] over the rows of row group rg
-                double x = qd[0][e];
-                x += __shfl_xor(x, 16);
-                x += __shfl_xor(x, 32);
-                const int m = 4 * mg4 + e;
-                if (rg4 == 0 && m < NT && 16 + i4 < NT) {
-                    dst[m * NT + 16 + i4] = x;
-                    dst[(16 + i4) * NT + m] = x;
-                }
-                // BB: lane (block b, j) register e = [task 16 + e][task 16 + j] over the rows b mod 16
-                double y = qd[1][e];
-#pragma unroll
-                for (int off = 4; off < 64; off <<= 1) y += __shfl_xor(y, off);
-                if (b4 == 0 && 16 + e < NT && 16 + i4 < NT) dst[(16 + e) * NT + 16 + i4] = y;
-            }
-        }
-    }
-}
-
-// second launch bound = waves per SIMD the register allocation must leave room for: the fp64 accumulators would
-// otherwise cost the N <= 8 and the N <= 16 kernels one resident wave each (measured: -9 % bandwidth)
-#ifndef SVDQ_GRAM64_WAVES8
-#define SVDQ_GRAM64_WAVES8 5
-#endif
-#ifndef SVDQ_GRAM64_WAVES16
-#define SVDQ_GRAM64_WAVES16 3
-#endif
-template <int NTP, int MODE, bool F64, bool FULL>
-__global__ __launch_bounds__(64, (F64 && (MODE == 0 || MODE == 4) && NTP <= 16) ? (NTP <= 8 ? SVDQ_GRAM64_WAVES8 : SVDQ_GRAM64_WAVES16) : 1) void k_gram(const SvdqParam *__restrict__ params,
-                                             const SvdqUnit *__restrict__ units,
-                                             const float *const *__restrict__ ptrs,
-                                             const int64_t *__restrict__ rows_dev, int NT, int center,
-                                             double *__restrict__ gram_part, int unit0,
-                                             const void *const *__restrict__ aux,
-                                             const int32_t *__restrict__ only,
-                                             const void *const *__restrict__ aux2, int order,
-                                             const int64_t *__restrict__ ustart) {
-    __shared__ __attribute__((aligned(16))) float X[NTP * XS];
-    gram_unit<NTP, MODE, F64, FULL>(X, unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, order), params, units, ptrs,
-                                    rows_dev, NT, center, gram_part, aux, only, aux2, ustart);
-}
+// svdq_project.hip -- pass 2 of the SVD-Hybrid compressor: U = Tc W -> fp16, mean, c = fp16(U)^T Tc (k_basis_project and its
+// N > 16 forms).  Helpers and the layout notes: svdq_stream.h.
+#include "svdq_stream.h"
 
 // ------------------------------------------------------------------------------------ pass 2
 __device__ __forceinline__ void copy_out(const void *lds_src, uint8_t *gdst, int nbytes, int lane) {
@@ -1924,81 +1069,6 @@ __global__ __launch_bounds__(64, SVDQ_Q_WAVES) void k_basis_project_q(
 }
 
 // ------------------------------------------------------------------------------------ launchers
-// idx: NULL or the device table of index lists (gather mode); base: NULL or the device table of base tensors
-// (minus-base mode); both may be given (masked parameters straight from checkpoints).  ustart: NULL, or the per-unit
-// source start positions of the walk mode -- idx is then the device table of combined MASK byte tensors.
-template <int NTP>
-static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                         int unit0, int nunits, int center, const void *idx, const void *base, int f64,
-                         const int32_t *only, const int64_t *ustart, hipStream_t st) {
-    auto pp = reinterpret_cast<const float *const *>(ptrs);
-    auto ai = (const void *const *)idx, ab = (const void *const *)base;
-#define SVDQ_LAUNCH_GRAM_(M, F, FULL_)                                                                                     \
-    hipLaunchKernelGGL((k_gram<NTP, M, F, FULL_>), dim3(nunits), dim3(64), 0, st, pl->d_params, pl->d_units, pp, rows_dev, \
-                       pl->n_tasks, center, gram_part, unit0, ai, only, ab, pl->cfg.reserved & 4, ustart)
-    // the plain and the mask-walk mode have a variant for plans with exactly NTP tasks
-#define SVDQ_LAUNCH_GRAM(M, F)                                                                                       \
-    do {                                                                                                             \
-        if constexpr ((M) == 0 || (M) == 4) {                                                                        \
-            if (pl->n_tasks == NTP) {                                                                                \
-                SVDQ_LAUNCH_GRAM_(M, F, true);                                                                       \
-                break;                                                                                               \
-            }                                                                                                        \
-        }                                                                                                            \
-        SVDQ_LAUNCH_GRAM_(M, F, false);                                                                              \
-    } while (0)
-    const int mode = ustart ? (4 | (base ? 2 : 0)) : ((idx ? 1 : 0) | (base ? 2 : 0));
-    if constexpr (NTP <= 16) {
-        if (mode & 4) {      // walk mode exists for the one-wave kernels (N <= 16), always with the default Gram
-            if (f64) {
-                if (mode == 4) SVDQ_LAUNCH_GRAM(4, true); else SVDQ_LAUNCH_GRAM(6, true);
-            } else {
-                if (mode == 4) SVDQ_LAUNCH_GRAM(4, false); else SVDQ_LAUNCH_GRAM(6, false);
-            }
-            return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
-        }
-    }
-    if (mode & 4) {
-        svdq_set_error("the mask-walk mode covers N <= 16 tasks (got %d): use the index lists (svdq_compress_gather)",
-                       pl->n_tasks);
-        return SVDQ_EUNSUPPORTED;
-    }
-    if (f64) {
-        switch (mode) {
-            case 0: SVDQ_LAUNCH_GRAM(0, true); break;
-            case 1: SVDQ_LAUNCH_GRAM(1, true); break;
-            case 2: SVDQ_LAUNCH_GRAM(2, true); break;
-            default: SVDQ_LAUNCH_GRAM(3, true); break;
-        }
-    } else {
-        switch (mode) {
-            case 0: SVDQ_LAUNCH_GRAM(0, false); break;
-            case 1: SVDQ_LAUNCH_GRAM(1, false); break;
-            case 2: SVDQ_LAUNCH_GRAM(2, false); break;
-            default: SVDQ_LAUNCH_GRAM(3, false); break;
-        }
-    }
-#undef SVDQ_LAUNCH_GRAM
-#undef SVDQ_LAUNCH_GRAM_
-    return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
-}
-
-// f64: accumulate the products with v_mfma_f64_16x16x4_f64 (exact) instead of fp32 MFMA; only: NULL, or a device
-// table [n_params] -- units of parameters whose entry is 0 return at once (the refinement pass of N > 16)
-int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, double *gram_part,
-                     int unit0, int nunits, int center, const void *idx, const void *base, int f64,
-                     const int32_t *only, hipStream_t st, const int64_t *ustart) {
-#define SVDQ_GRAM_CASE(n) \
-    case n: return launch_gram_t<n>(pl, ptrs, rows_dev, gram_part, unit0, nunits, center, idx, base, f64, only, ustart, st)
-    switch (pl->ntp) {
-        SVDQ_GRAM_CASE(4); SVDQ_GRAM_CASE(8); SVDQ_GRAM_CASE(12); SVDQ_GRAM_CASE(16);
-        SVDQ_GRAM_CASE(20); SVDQ_GRAM_CASE(24); SVDQ_GRAM_CASE(28); SVDQ_GRAM_CASE(32);
-    }
-#undef SVDQ_GRAM_CASE
-    svdq_set_error("unsupported padded task count %d", pl->ntp);
-    return SVDQ_EUNSUPPORTED;
-}
-
 template <int NTP, bool F16>
 static int launch_bp_mode(const svdq_plan *pl, const float *const *pp, const int64_t *rows_dev, const float *W,
                           const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
@@ -2090,3 +1160,4 @@ int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64
     svdq_set_error("unsupported padded task count %d", pl->ntp);
     return SVDQ_EUNSUPPORTED;
 }
+

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of build variants of the streaming kernels (SVDQ_LIB_PATH selects the library); prints ms/step and kernels.
-# Variants are built by hand, e.g.:  hipcc ... -DSVDQ_UNROLL_BP2=2 -c svdq_stream.hip -o build/stream_a.o; link as var_a.so
+# Variants are built by hand, e.g.:  hipcc ... -DSVDQ_UNROLL_BP2=2 -c svdq_project.hip -o build/project_a.o; link as var_a.so
 for cfg in ${CFGS:-ViT-L-14:20 ViT-L-14:32}; do m=${cfg%%:*}; n=${cfg##*:}
 for v in libsvdq_hip var_a var_b var_c; do
   [ -f svd-quantization-task-merging_amd/$v.so ] || continue

@@ -1,5 +1,5 @@
 """Would U_high and U_low in DIFFERENT memory regions help pass 2 further?  Experiment build only
-(svd-quantization-task-merging_amd/var_ulow.so: svdq_stream.hip compiled with -DSVDQ_EXP_ULOW_SHIFT=8 GiB, so U_low of every
+(svd-quantization-task-merging_amd/var_ulow.so: svdq_project.hip compiled with -DSVDQ_EXP_ULOW_SHIFT=8 GiB, so U_low of every
 parameter is written 8 GiB behind its slab), selected with SVDQ_LIB_PATH.  Same harness as placement_probe6.py: one
 huge allocation cut into 4 GiB slots, slots classified by the copy probe; the basis then starts in a slot o whose
 slots o, o+1 lie in one region and o+2, o+3 in another, the mean and the deltas go into chosen regions."""
