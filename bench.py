@@ -99,6 +99,9 @@ def parse():
                          "merged delta, fp32) resident in HBM; a step = svdq_merge over the whole plan (coefficient "
                          "averaging from the small-artifact buffer + one streaming reconstruction).  --clusters K "
                          "merges K clusters of tasks and combines them with softmax shares in the same pass")
+    ap.add_argument("--diagnostics", action="store_true",
+                    help="time the plan-level diagnostics (all N error tuples of every parameter from one pass over U and "
+                         "the N deltas: svdq_diagnostics / svdq_diagnostics_masked) instead of the compression")
     ap.add_argument("--clusters", type=int, default=1, help="--merge: number of task clusters (sets), 1..8")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -480,7 +483,13 @@ def merge_leg(wl, args, dev):
     from svdq_amd.pipeline import _ptr, _stream_ptr
     plan, N, S = wl.plan, args.tasks, max(1, min(args.clusters, 8, args.tasks))
     lib = wl.lib
-    plan.run(wl.table)
+    masked = args.masks != "none"
+    if masked:
+        if not wl.walk:
+            sys.exit("bench.py --merge with masks: the mask-walk mode (N <= 16, no --masks-index / --masks-compact)")
+        wl.step()      # vote + scan + unit starts + the masked compression: leaves the mask table and the unit starts
+    else:
+        plan.run(wl.table)
     torch.cuda.synchronize()
     wt = np.full((S, N), -1.0, dtype=np.float32)
     for t in range(N):
@@ -496,16 +505,26 @@ def merge_leg(wl, args, dev):
     btab = torch.tensor([b.data_ptr() for b in base], dtype=torch.int64).to(dev)
     buf, offs, otab = plan.merged_outputs()
     work = torch.empty(int(lib.svdq_merge_work_bytes(plan._h, S)), dtype=torch.uint8, device=dev)
+    fill = torch.ones(plan.P, dtype=torch.int32, device=dev)      # no noise regions: the signal entries write every row
     steps, warm = args.steps, args.warmup
+    kname = "k_merge_expand" if masked else "k_merge_reconstruct"
 
     def step(ev=None):
         if ev is not None:
             ev[0].record()
-        lib.svdq_merge_coeffs(plan._h, _ptr(plan.small), _ptr(wt_d), c_void_p(0), S, 0, _ptr(work), _stream_ptr())
+        if not masked:
+            lib.svdq_merge_coeffs(plan._h, _ptr(plan.small), _ptr(wt_d), c_void_p(0), S, 0, _ptr(work), _stream_ptr())
         if ev is not None:
             ev[1].record()
-        rc = lib.svdq_merge_reconstruct(plan._h, c_void_p(0), _ptr(plan.small), _ptr(plan.basis), _ptr(plan.mean),
-                                        _ptr(work), S, 0, _ptr(sh_d), c_void_p(0), _ptr(btab), _ptr(otab), _stream_ptr())
+        if masked:
+            # one entry point for both launches: the second interval holds k_merge_coeff (~6 us) too
+            rc = lib.svdq_merge_masked(plan._h, _ptr(wl.rows_dev), _ptr(plan.small), _ptr(plan.basis), _ptr(plan.mean),
+                                       _ptr(wt_d), c_void_p(0), S, 0, _ptr(sh_d), c_void_p(0), _ptr(wl.mtab),
+                                       _ptr(wl.ustart), _ptr(fill), _ptr(btab), _ptr(otab), _ptr(work), _stream_ptr())
+        else:
+            rc = lib.svdq_merge_reconstruct(plan._h, c_void_p(0), _ptr(plan.small), _ptr(plan.basis), _ptr(plan.mean),
+                                            _ptr(work), S, 0, _ptr(sh_d), c_void_p(0), _ptr(btab), _ptr(otab),
+                                            _stream_ptr())
         if ev is not None:
             ev[2].record()
         assert rc == 0, rc
@@ -522,6 +541,9 @@ def merge_leg(wl, args, dev):
     sumD = float(sum(wl.rows))
     # algorithmic bytes of the streaming launch: U fp16 (2 N) + mean + base read, fp32 out written
     rec_bytes = sumD * (2 * N + 12)
+    if masked:      # basis and mean per SELECTED row; mask byte, base and output per source row
+        sel = float(wl.rows_dev.sum().item())
+        rec_bytes = sel * (2 * N + 4) + sumD * 9
     gbs = rec_bytes / (kms[1] * 1e-3) / 1e9
     ms = elapsed / steps * 1e3
     return {
@@ -532,11 +554,61 @@ def merge_leg(wl, args, dev):
         "config": {"workload": f"{args.model} visual encoder x {N} tasks: merge of the compressed artifacts, "
                                f"{S} cluster(s), + base (apply_merged_deltas fused), {len(wl.rows)} tensors, "
                                f"sum D = {int(sumD)}", "tasks": N, "clusters": S,
-                   "schedule": "2 kernels: merge_coeff, merge_reconstruct"},
-        "roofline": {"bound": "hbm", "kernel": "k_merge_reconstruct", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                   "masks": (f"{args.masks} of {N} per-task masks, reconstruct_from_masked inside the streaming launch"
+                             if masked else None),
+                   "schedule": f"2 kernels: merge_coeff, {kname[2:]}"},
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes": int(rec_bytes), "avg_ms": round(kms[1], 4)},
-        "kernels_ms": {"k_merge_coeff": round(kms[0], 4), "k_merge_reconstruct": round(kms[1], 4)},
+        "kernels_ms": ({"k_merge_coeff + k_merge_expand": round(kms[1], 4)} if masked else
+                       {"k_merge_coeff": round(kms[0], 4), kname: round(kms[1], 4)}),
+    }
+
+
+def diagnostics_leg(wl, args, dev):
+    """--diagnostics: K timed steps of compute_all_diagnostics' device part for the whole plan after one compression
+    (k_one_hot + k_merge_coeff + k_diag / k_diag_walk + k_diag_finish); returns the JSON fields."""
+    plan, N = wl.plan, args.tasks
+    masked = args.masks != "none"
+    if masked and not wl.walk:
+        sys.exit("bench.py --diagnostics with masks: the mask-walk mode (N <= 16, no --masks-index / --masks-compact)")
+    wl.step()
+    torch.cuda.synchronize()
+
+    def step():
+        if masked:
+            return plan.diagnostics_masked(wl.table, wl.mtab, wl.ustart, wl.rows_dev)
+        return plan.diagnostics(wl.table)
+    for _ in range(args.warmup):
+        step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for s_ in range(args.steps):
+        step()
+        ev[s_ + 1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)) / args.steps
+    sumD = float(sum(wl.rows))
+    sel = float(wl.rows_dev.sum().item()) if masked else sumD
+    # the N deltas at every source row (+ the mask byte), the fp16 basis at every selected row; no mean (SURVEY Q1)
+    nbytes = sumD * (4 * N + (1 if masked else 0)) + sel * 2 * N
+    gbs = nbytes / (kms * 1e-3) / 1e9
+    kname = "k_diag_walk" if masked else "k_diag"
+    return {
+        "metric": "MParams/s diagnosed (deltas + artifacts in HBM -> N error tuples per parameter; Params = N_tasks * sum D_p)",
+        "value": round(sumD * N / (elapsed / args.steps) / 1e6, 1), "unit": "MParams/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "none", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} visual encoder x {N} tasks: reconstruction-error diagnostics of every "
+                               f"(parameter, task), {len(wl.rows)} tensors, sum D = {int(sumD)}", "tasks": N,
+                   "masks": f"{args.masks} of {N} per-task masks, selection inside the pass" if masked else None,
+                   "schedule": f"4 kernels: one_hot, merge_coeff, {kname[2:]}, diag_finish"},
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(nbytes),
+                     "avg_ms": round(kms, 4), "note": "avg_ms spans the four launches (the three small ones ~20 us)"},
     }
 
 
@@ -605,11 +677,16 @@ def main():
                 f.write(open("/proc/self/maps").read())
         except OSError:
             pass
+    if args.diagnostics:
+        if world > 1 or args.from_base != "off":
+            sys.exit("bench.py --diagnostics: one GPU, task vectors resident")
+        print(json.dumps(diagnostics_leg(wl, args, dev)), flush=True)
+        return
     if args.merge:
-        if world > 1 or args.masks != "none" or args.from_base != "off":
-            sys.exit("bench.py --merge: one GPU, unmasked task vectors")
+        if world > 1 or args.from_base != "off":
+            sys.exit("bench.py --merge: one GPU, task vectors resident")
         out = merge_leg(wl, args, dev)
-        if not args.no_cpu:
+        if not args.no_cpu and args.masks == "none":      # the oracle's merge restatement has no mask scatter
             out["cpu_baseline"] = cpu_merge_baseline(names, rows, N, args)
         print(json.dumps(out), flush=True)
         return

@@ -428,6 +428,28 @@ int svdq_diagnostics(const svdq_plan *plan, const void *delta_ptrs_dev, const in
                      const void *basis_dev, const float *mean_dev, int32_t add_mean, double *out_dev, void *work_dev,
                      void *stream);
 
+/* ---- the same for MASKED regions, with reconstruct_from_masked (mask_loader.py:712-763: zeros; result[mask] = signal;
+ *      result[~mask] = noise) and apply_mask_to_tensor (:651-679, the "original" of the masked diagnostics,
+ *      diagnostics.py:186-199) inside the streaming launch: the plan's artifacts describe the COMPACTED rows of every
+ *      region; the launch walks the SOURCE rows with the combined mask byte beside them (mask_ptrs_dev [P], unit_start_dev
+ *      [plan units] from svdq_maskset_unit_starts / *_starts; bit 62 of a start = the region is the CLEARED elements),
+ *      finds each selected row's compacted row by wave ballots and reads the contiguous run of basis rows it needs.
+ *   svdq_merge_masked: out_ptrs_dev [P] = FULL tensors (params[p].rows elements; NULL = leave this entry alone); every
+ *     selected source row gets the merged value of its compacted row (+ base at the source row); fill_dev NULL or int32
+ *     [P]: 1 = the entry also writes 0 (+ base) to the rows its region does not select -- for a signal region without a
+ *     noise region; with one, the noise entry (its own plan entry, inverted polarity, scale = noise_shrink) writes
+ *     them.  Same bits as svdq_merge + svdq_mask_expand (+ base).
+ *   svdq_diagnostics_masked: delta_ptrs_dev = the N unmasked task deltas per entry. */
+int svdq_merge_masked(const svdq_plan *plan, const int64_t *rows_dev, const void *small_dev, const void *basis_dev,
+                      const float *mean_dev, const float *weights_dev, const int32_t *order_dev, int32_t n_sets,
+                      int32_t per_param, const float *set_share_dev, const float *scale_dev, const void *mask_ptrs_dev,
+                      const int64_t *unit_start_dev, const int32_t *fill_dev, const void *base_ptrs_dev,
+                      const void *out_ptrs_dev, void *work_dev, void *stream);
+int svdq_diagnostics_masked(const svdq_plan *plan, const void *delta_ptrs_dev, const void *mask_ptrs_dev,
+                            const int64_t *unit_start_dev, const int64_t *rows_dev, const void *small_dev,
+                            const void *basis_dev, const float *mean_dev, int32_t add_mean, double *out_dev,
+                            void *work_dev, void *stream);
+
 /* ---- measurement aid (no reference counterpart; SURVEY.md section 8d asks for "a measured device-copy ceiling on
  *      the box" beside the 8 TB/s specification): plain streaming kernels with the access shape of the two passes.
  *      mode 0: read `bytes` from src_dev (dst_dev receives one float per 256 KiB read); mode 1: copy `bytes`;

@@ -120,6 +120,11 @@ SIGNATURES = {
     "svdq_diagnostics_work_bytes": (c_int64, [c_void_p]),
     "svdq_diagnostics": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                    c_void_p, c_void_p]),
+    "svdq_merge_masked": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                    c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "svdq_diagnostics_masked": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int32, c_void_p, c_void_p, c_void_p]),
     "svdq_mask_expand": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "svdq_hbm_probe": (c_int32, [c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
 }

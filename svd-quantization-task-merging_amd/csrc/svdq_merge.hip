@@ -23,6 +23,13 @@
 
 #define MRG_MAX_SETS 8
 
+// pointers read out of device tables are generic to the compiler: without the address space it emits flat_load /
+// flat_store, which count on lgkmcnt as well and so make every LDS wait a wait for HBM
+typedef const __attribute__((address_space(1))) float mg_gfloat;
+typedef __attribute__((address_space(1))) float mg_gfloat_w;
+typedef const __attribute__((address_space(1))) uint8_t mg_gbyte;
+typedef const __attribute__((address_space(1))) f32x4 mg_gf32x4;
+
 // ------------------------------------------------------------------------------------ coefficients
 // weights [P or 1][n_sets][N]: weight of task t inside set s, renormalised over the set's present tasks by the caller
 // exactly as the reference does on the host (merge.py:123-124); < 0 = the task is not in the set.
@@ -132,9 +139,9 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
     const uint8_t *slab = basis + params[p].slab_off;
     const uint8_t *gUh = slab;
     const uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
-    const float *gmean = meanbuf ? meanbuf + params[p].mean_off : nullptr;
-    const float *gbase = base_ptrs ? base_ptrs[p] : nullptr;
-    float *gout = out_ptrs[p];
+    mg_gfloat *gmean = meanbuf ? (mg_gfloat *)(meanbuf + params[p].mean_off) : nullptr;
+    mg_gfloat *gbase = base_ptrs ? (mg_gfloat *)base_ptrs[p] : nullptr;
+    mg_gfloat_w *gout = (mg_gfloat_w *)out_ptrs[p];
     T *Uh = UT, *Ul = UT + SVDQ_BLK_ROWS * k;
 
     for (int64_t rb = r_begin; rb < r_end; rb += SVDQ_BLK_ROWS) {
@@ -199,6 +206,198 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
     }
 }
 
+// ------------------------------------------------------------------------------------ masked parameters: source walk
+// reconstruct_from_masked (mask_loader.py:712-763) fused into the merge: the artifacts of a masked region describe the
+// COMPACTED rows, the merged tensor wants them back at their source positions.  A unit of the plan owns the source rows
+// from its first selected element (ustart[u], svdq_maskset_*_starts -- the table the mask-walk compressor uses) to the
+// next unit's; the first unit of a parameter starts at 0, the last ends with the tensor.  Per chunk of 256 source rows
+// (lane l owns rows src + 64 e + l: every load and store is 256 contiguous bytes):
+//   mask bytes -> four ballots -> compacted row of every selected source row (no index list, no scan through memory);
+//   the chunk's run of basis rows [cpos, cpos + selected) is contiguous in U_high / U_low: staged in LDS by 16-byte loads;
+//   selected rows get the merged value (same per-row arithmetic as k_merge_reconstruct), the others 0 when ``fill``
+//   (no noise region writes them) or are left to the noise region's launch; base is added at the SOURCE row.
+#define MRG_POS_MASK ((1ll << 62) - 1)      // ustart: bit 62 = the region takes the cleared mask elements
+
+struct SrcRange {
+    int64_t lo, hi;
+    int inv;
+};
+__device__ __forceinline__ SrcRange unit_source_range(const SvdqParam &pd, int u, const int64_t *__restrict__ ustart) {
+    const int64_t us = ustart[u];
+    SrcRange s;
+    s.inv = (int)((us >> 62) & 1);
+    s.lo = (u == pd.unit_begin) ? 0 : (us & MRG_POS_MASK);
+    s.hi = (u == pd.unit_begin + pd.unit_count - 1) ? pd.rows : (ustart[u + 1] & MRG_POS_MASK);
+    return s;
+}
+
+// rows [c0, c0 + n) of a row-major [rows, w] basis part -> LDS with aligned 16-byte loads (the part starts 256-aligned
+// and is padded to 256 bytes, so rounding both ends to 16 stays inside it); returns the element offset of row c0
+template <int ES>
+__device__ __forceinline__ int stage_rows(uint8_t *lds, const uint8_t *g, int64_t c0, int n, int w, int lane) {
+    const int64_t b0 = c0 * w * ES, b1 = (c0 + n) * (int64_t)w * ES;
+    const int64_t a0 = b0 & ~15ll;
+    const int nvec = (int)((b1 - a0 + 15) >> 4);
+    mg_gf32x4 *s4 = (mg_gf32x4 *)(g + a0);
+    f32x4 *d4 = reinterpret_cast<f32x4 *>(lds);
+    for (int i = lane; i < nvec; i += 64) d4[i] = s4[i];
+    return (int)(b0 - a0) / ES;
+}
+
+// the chunk's selection: rank of each of the lane's four rows among the chunk's selected rows, and their number
+struct ChunkSel {
+    bool in[4], sel[4];
+    int rank[4];
+    int count;
+};
+__device__ __forceinline__ ChunkSel chunk_select(mg_gbyte *__restrict__ gmask, int64_t src, int64_t hi, int inv,
+                                                 int64_t room, int lane) {
+    ChunkSel c;
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t r = src + 64 * e + lane;
+        c.in[e] = r < hi;
+        const unsigned mk = c.in[e] ? (unsigned)gmask[r] : 0x100u;
+        const bool s = inv ? (mk == 0u) : (mk != 0u && mk != 0x100u);
+        const unsigned long long bal = __ballot(s);
+        c.rank[e] = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        c.sel[e] = s && c.rank[e] < room;      // never past the unit's compacted rows, whatever the mask says
+        base += (int)__popcll(bal);
+    }
+    c.count = base < room ? base : (int)room;
+    return c;
+}
+
+template <bool U16, int NS>
+__global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict__ params,
+                                                     const SvdqUnit *__restrict__ units,
+                                                     const int64_t *__restrict__ rows_dev, int NT, int n_sets,
+                                                     int per_param, const int32_t *__restrict__ k_in,
+                                                     const int32_t *__restrict__ r_in,
+                                                     const uint8_t *__restrict__ basis,
+                                                     const float *__restrict__ meanbuf, const float *__restrict__ cbar,
+                                                     const float *__restrict__ set_share,
+                                                     const float *__restrict__ scale_tab,
+                                                     const uint8_t *const *__restrict__ mask_ptrs,
+                                                     const int64_t *__restrict__ ustart,
+                                                     const int32_t *__restrict__ fill_tab,
+                                                     const float *const *__restrict__ base_ptrs,
+                                                     float *const *__restrict__ out_ptrs) {
+    using T = typename UElem<U16>::type;
+    constexpr int ES = U16 ? 2 : 4;
+    // dynamic LDS: the two staged runs of basis rows (each up to 256 rows + 16 bytes of alignment slack), the coefficients
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    float *C = reinterpret_cast<float *>(lds_raw + (size_t)SVDQ_BLK_ROWS * NT * ES + 64);   // [column][NS]
+    float *SH = C + NS * NT;
+    const int lane = threadIdx.x, u = blockIdx.x;
+    const SvdqUnit ud = units[u];
+    const int p = ud.param;
+    mg_gfloat_w *gout = (mg_gfloat_w *)out_ptrs[p];
+    if (!gout) return;      // an entry the caller does not merge
+    const SvdqParam pd = params[p];
+    const SrcRange sr = unit_source_range(pd, u, ustart);
+    if (sr.lo >= sr.hi) return;
+    const int64_t D = rows_dev ? rows_dev[p] : pd.rows;      // compacted rows of the region
+    int64_t cpos = ud.row0;
+    int64_t cend = ud.row0 + ud.nrows;
+    if (cend > D) cend = D;
+    if (cpos > cend) cpos = cend;
+    const int k = k_in[p], r = r_in[p], nl = r - k, n = NT;
+    for (int e = lane; e < NS * n; e += 64) {
+        const int i = e / NS, s = e % NS;
+        C[e] = s < n_sets ? cbar[((size_t)p * n_sets + s) * n + i] : 0.f;
+    }
+    if (lane < NS)
+        SH[lane] = (set_share && lane < n_sets) ? set_share[(per_param ? (size_t)p * n_sets : 0) + lane] : -1.f;
+    const float scale = scale_tab ? scale_tab[p] : 1.f;
+    const bool fill = fill_tab ? fill_tab[p] != 0 : false;
+    const uint8_t *slab = basis + pd.slab_off;
+    const uint8_t *gUh = slab;
+    const uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
+    mg_gfloat *gmean = meanbuf ? (mg_gfloat *)(meanbuf + pd.mean_off) : nullptr;
+    mg_gfloat *gbase = base_ptrs ? (mg_gfloat *)base_ptrs[p] : nullptr;
+    mg_gbyte *gmask = (mg_gbyte *)mask_ptrs[p];
+    uint8_t *ldsUh = lds_raw;
+    uint8_t *ldsUl = lds_raw + svdq_align_up((int64_t)SVDQ_BLK_ROWS * k * ES + 16, 16);
+
+    for (int64_t src = sr.lo; src < sr.hi; src += SVDQ_BLK_ROWS) {
+        const ChunkSel cs = chunk_select(gmask, src, sr.hi, sr.inv, cend - cpos, lane);
+        int offh = 0, offl = 0;
+        if (cs.count > 0) {
+            if (k > 0) offh = stage_rows<ES>(ldsUh, gUh, cpos, cs.count, k, lane);
+            if (nl > 0) offl = stage_rows<ES>(ldsUl, gUl, cpos, cs.count, nl, lane);
+        }
+        float mv[4], bv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            mv[m] = (gmean && cs.sel[m]) ? gmean[cpos + cs.rank[m]] : 0.f;
+            bv[m] = (gbase && cs.in[m]) ? gbase[src + 64 * m + lane] : 0.f;
+        }
+        lds_fence();
+        float res[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cs.count > 0) {
+            const T *Uh = reinterpret_cast<const T *>(ldsUh) + offh;
+            const T *Ul = reinterpret_cast<const T *>(ldsUl) + offl;
+            int rl[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) rl[m] = cs.sel[m] ? cs.rank[m] : 0;
+            float hi[4][NS], lo[4][NS];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) hi[m][s] = lo[m][s] = 0.f;
+            for (int i = 0; i < k; ++i) {
+                float c[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) c[s] = C[i * NS + s];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float uv = u_val(Uh, rl[m] * k + i);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) hi[m][s] = fmaf(uv, c[s], hi[m][s]);
+                }
+            }
+            for (int j = 0; j < nl; ++j) {
+                float c[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) c[s] = C[(k + j) * NS + s];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float uv = u_val(Ul, rl[m] * nl + j);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) lo[m][s] = fmaf(uv, c[s], lo[m][s]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float acc = 0.f;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    float v = __fadd_rn(hi[m][s], lo[m][s]);
+                    if (gmean) v = __fadd_rn(v, mv[m]);
+                    v = __fmul_rn(v, scale);
+                    if (set_share) {
+                        if (SH[s] >= 0.f) acc = __fadd_rn(acc, __fmul_rn(v, SH[s]));
+                    } else if (s == 0) {
+                        acc = v;
+                    }
+                }
+                res[m] = cs.sel[m] ? acc : 0.f;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (cs.in[m] && (cs.sel[m] || fill)) {
+                const float v = gbase ? __fadd_rn(bv[m], res[m]) : res[m];      // base + delta (merge.py:429-552)
+                gout[src + 64 * m + lane] = v;
+            }
+        }
+        lds_fence();
+        cpos += cs.count;
+    }
+}
+
 // ------------------------------------------------------------------------------------ diagnostics
 // One pass over U and the N task deltas of a parameter: per task t the reconstruction U_high c_high[t] + U_low c_low[t]
 // (+ mean when add_mean: the reference's diagnostics do NOT add it back) is formed per row and compared with
@@ -207,106 +406,290 @@ struct DiagPart {
     double se, sx, sr, sa, mx;
 };
 
-template <int NTP, bool U16>
-__global__ __launch_bounds__(64) void k_diag(const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
-                                             const float *const *__restrict__ ptrs,
-                                             const int64_t *__restrict__ rows_dev, int NT,
-                                             const int32_t *__restrict__ k_in, const int32_t *__restrict__ r_in,
-                                             const uint8_t *__restrict__ basis, const float *__restrict__ meanbuf,
-                                             int add_mean, const float *__restrict__ ctask /* [P][N][N] */,
-                                             DiagPart *__restrict__ part /* [n_units][N] */) {
+// A workgroup of W = ceil(N / 8) wavefronts per work unit; wavefront w owns tasks 8 w .. 8 w + 7 for ALL rows, so its
+// running sums (5 per task) stay in registers.  A block is up to 256 rows; lane l owns rows l, 64 + l, 128 + l, 192 + l.
+// Software pipeline, one block deep: while block b is computed from LDS, the loads of block b + 1 are in flight into
+// registers -- its N deltas (dword loads, 256 contiguous bytes per task and instruction), its run of basis rows (16-byte
+// loads, shared by the W wavefronts) and, in walk mode, its mask bytes.  Per block: registers -> LDS (deltas to the
+// wavefront's own X[task][row] strip, basis rows to one of two shared buffers), one barrier, issue the next block's
+// loads, compute.  The per-row arithmetic is k_recon_error's: fp32 fma chains over the columns, hi + lo (+ mean), fp64 sums.
+// WALK: the block is a chunk of 256 SOURCE rows of a masked region (k_merge_expand's walk); selected rows are written
+// to X at their rank, so the compute phase is the same loop over `count` compacted rows.  The next chunk's basis run
+// starts where this one ends; its length is not known before its mask is, so 256 rows (clamped to the unit) are fetched.
+#define DG_TPW 8
+#define DG_XS (SVDQ_BLK_ROWS + 64)      // X row: 256 rows + one dump slot per lane (unselected rows are written there: no branch)
+
+struct UStage {      // where a block's staged basis rows sit (wave-uniform)
+    int nvh, nv;     // 16-byte vectors of the U_high part, of both parts
+    int offh, offl;  // element offset of the block's first row inside each part
+    int64_t a0h, a0l;
+};
+template <int ES>
+__device__ __forceinline__ UStage ustage_plan(int64_t c0, int nr, int k, int nl) {
+    UStage u;
+    const int64_t b0h = c0 * k * ES, b1h = (c0 + nr) * (int64_t)k * ES;
+    const int64_t b0l = c0 * nl * ES, b1l = (c0 + nr) * (int64_t)nl * ES;
+    u.a0h = b0h & ~15ll;
+    u.a0l = b0l & ~15ll;
+    u.nvh = k > 0 ? (int)((b1h - u.a0h + 15) >> 4) : 0;
+    u.nv = u.nvh + (nl > 0 ? (int)((b1l - u.a0l + 15) >> 4) : 0);
+    u.offh = (int)(b0h - u.a0h) / ES;
+    u.offl = (int)(b0l - u.a0l) / ES;
+    return u;
+}
+
+template <int W, bool U16, bool WALK>
+__global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict__ params,
+                                                  const SvdqUnit *__restrict__ units,
+                                                  const float *const *__restrict__ ptrs,
+                                                  const uint8_t *const *__restrict__ mask_ptrs,
+                                                  const int64_t *__restrict__ ustart,
+                                                  const int64_t *__restrict__ rows_dev, int NT,
+                                                  const int32_t *__restrict__ k_in, const int32_t *__restrict__ r_in,
+                                                  const uint8_t *__restrict__ basis, const float *__restrict__ meanbuf,
+                                                  int add_mean, const float *__restrict__ ctask /* [P][N][N] */,
+                                                  DiagPart *__restrict__ part /* [n_units][N] */) {
     using T = typename UElem<U16>::type;
     constexpr int ES = U16 ? 2 : 4;
-    __shared__ __attribute__((aligned(16))) T UT[SVDQ_BLK_ROWS * NTP];
-    __shared__ float C[NTP * NTP];
-    const int lane = threadIdx.x, n = NT;
-    const SvdqUnit ud = units[blockIdx.x];
+    // 16-byte vectors of one block's basis rows per thread: 256 rows x 8 W columns x ES bytes over 64 W threads, + ends
+    constexpr int SV = (SVDQ_BLK_ROWS * DG_TPW * ES / 16) / 64 + 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = NT, u = blockIdx.x;
+    const int ubytes = (int)svdq_align_up((int64_t)SVDQ_BLK_ROWS * n * ES + 64, 16);
+    uint8_t *Ubuf = lds_raw;                                                  // two buffers
+    float *Cw = reinterpret_cast<float *>(lds_raw + 2 * ubytes) + (size_t)w * n * DG_TPW;   // [column][8 tasks] per wave
+    float *Xw = reinterpret_cast<float *>(lds_raw + 2 * ubytes) + (size_t)W * n * DG_TPW +
+                (size_t)w * (DG_TPW + 1) * DG_XS;                             // [8 tasks + mean][256 rows + dump] per wave
+    const int t0 = w * DG_TPW;
+    const int nt = (n - t0 < DG_TPW) ? (n - t0) : DG_TPW;      // tasks of this wave (>= 1: W = ceil(N / 8))
+    const SvdqUnit ud = units[u];
     const int p = ud.param;
-    const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
-    const int64_t r_begin = ud.row0;
-    int64_t r_end = r_begin + ud.nrows;
-    if (r_end > D) r_end = D;
-    const int k = k_in[p], r = r_in[p], nl = r - k;
-    double se[NTP], sx[NTP], sr[NTP], sa[NTP];
-    float mx[NTP];
+    const SvdqParam pd = params[p];
+    const int64_t D = rows_dev ? rows_dev[p] : pd.rows;
+    int64_t cpos = ud.row0;
+    int64_t cend = ud.row0 + ud.nrows;
+    if (cend > D) cend = D;
+    double se[DG_TPW], sx[DG_TPW], sr[DG_TPW], sa[DG_TPW];
+    float mx[DG_TPW];
 #pragma unroll
-    for (int t = 0; t < NTP; ++t) {
-        se[t] = sx[t] = sr[t] = sa[t] = 0.0;
-        mx[t] = 0.f;
+    for (int a = 0; a < DG_TPW; ++a) {
+        se[a] = sx[a] = sr[a] = sa[a] = 0.0;
+        mx[a] = 0.f;
     }
-    if (r_begin < r_end) {
-        for (int e = lane; e < n * n; e += 64) C[e] = ctask[(size_t)p * n * n + e];
-        const uint8_t *slab = basis + params[p].slab_off;
+    if (cpos < cend) {      // workgroup-uniform
+        const int k = k_in[p], r = r_in[p], nl = r - k;
+        for (int e = lane; e < n * DG_TPW; e += 64) {      // this wave's coefficient table, [column][task]
+            const int c = e / DG_TPW, a = e % DG_TPW;
+            Cw[e] = (a < nt) ? ctask[(size_t)p * n * n + (size_t)(t0 + a) * n + c] : 0.f;
+        }
+        const uint8_t *slab = basis + pd.slab_off;
         const uint8_t *gUh = slab;
         const uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
-        const float *gmean = (add_mean && meanbuf) ? meanbuf + params[p].mean_off : nullptr;
-        const float *dp[NTP];
+        mg_gfloat *gmean = (add_mean && meanbuf) ? (mg_gfloat *)(meanbuf + pd.mean_off) : nullptr;
+        mg_gbyte *gmask = WALK ? (mg_gbyte *)mask_ptrs[p] : nullptr;
+        mg_gfloat *dp[DG_TPW];
 #pragma unroll
-        for (int t = 0; t < NTP; ++t) dp[t] = ptrs[(size_t)p * n + (t < n ? t : n - 1)];
-        T *Uh = UT, *Ul = UT + SVDQ_BLK_ROWS * k;
-        for (int64_t rb = r_begin; rb < r_end; rb += SVDQ_BLK_ROWS) {
-            const int rows_blk = (int)((D - rb < SVDQ_BLK_ROWS) ? (D - rb) : SVDQ_BLK_ROWS);
-            if (k > 0) copy_in(Uh, gUh + rb * (int64_t)k * ES, rows_blk * k * ES, lane);
-            if (nl > 0) copy_in(Ul, gUl + rb * (int64_t)nl * ES, rows_blk * nl * ES, lane);
-            lds_fence();
+        for (int a = 0; a < DG_TPW; ++a) dp[a] = (mg_gfloat *)ptrs[(size_t)p * n + t0 + (a < nt ? a : 0)];
+        int64_t src = cpos, src_hi = cend;      // plain: source rows = compacted rows
+        int inv = 0;
+        if constexpr (WALK) {
+            const SrcRange rg = unit_source_range(pd, u, ustart);
+            src = ustart[u] & MRG_POS_MASK;      // nothing is selected in front of the unit's first element
+            src_hi = rg.hi;
+            inv = rg.inv;
+        }
+        // ---- the loads of one block into registers
+        float xpf[DG_TPW][4] = {}, mpf[4];
+        unsigned mkpf[4];
+        f32x4 ureg[SV];
+        UStage us;
+        auto prefetch = [&](int64_t s0, int64_t c0) {
+            const int64_t r0 = s0 + lane;
+            if (s0 + SVDQ_BLK_ROWS <= src_hi) {      // the whole chunk is in range (all but a unit's last): plain loads
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int rl = 64 * m + lane;
-                if (rl < rows_blk) {
-                    float x[NTP];
+                for (int e = 0; e < 4; ++e)
+                    if constexpr (WALK) mkpf[e] = (unsigned)gmask[r0 + 64 * e];
 #pragma unroll
-                    for (int t = 0; t < NTP; ++t) x[t] = (t < n) ? dp[t][rb + rl] : 0.f;
-                    const float mval = gmean ? gmean[rb + rl] : 0.f;
-                    float hi[NTP], lo[NTP];
+                for (int a = 0; a < DG_TPW; ++a)
+                    if (a < nt) {      // wave-uniform
 #pragma unroll
-                    for (int t = 0; t < NTP; ++t) hi[t] = lo[t] = 0.f;
-                    for (int i = 0; i < k; ++i) {
-                        const float u = u_val(Uh, rl * k + i);
-#pragma unroll
-                        for (int t = 0; t < NTP; ++t) hi[t] = fmaf(u, C[(t < n ? t : 0) * n + i], hi[t]);
+                        for (int e = 0; e < 4; ++e) xpf[a][e] = dp[a][r0 + 64 * e];
                     }
-                    for (int j = 0; j < nl; ++j) {
-                        const float u = u_val(Ul, rl * nl + j);
+            } else {
+                bool in[4];
 #pragma unroll
-                        for (int t = 0; t < NTP; ++t) lo[t] = fmaf(u, C[(t < n ? t : 0) * n + k + j], lo[t]);
+                for (int e = 0; e < 4; ++e) {
+                    in[e] = r0 + 64 * e < src_hi;
+                    if constexpr (WALK) mkpf[e] = in[e] ? (unsigned)gmask[r0 + 64 * e] : 0x100u;
+                }
+#pragma unroll
+                for (int a = 0; a < DG_TPW; ++a)
+                    if (a < nt) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xpf[a][e] = in[e] ? dp[a][r0 + 64 * e] : 0.f;
                     }
+            }
+            const int nr = (int)((cend - c0 < SVDQ_BLK_ROWS) ? (cend - c0) : SVDQ_BLK_ROWS);
+            if (gmean) {      // (add_mean only) compacted rows c0 + 64 e + lane: no global load is left in the compute phase
 #pragma unroll
-                    for (int t = 0; t < NTP; ++t) {
-                        float rec = __fadd_rn(hi[t], lo[t]);
-                        if (gmean) rec = __fadd_rn(rec, mval);
-                        const float e = __fsub_rn(x[t], rec);
-                        se[t] += (double)e * e;
-                        sx[t] += (double)x[t] * x[t];
-                        sr[t] += (double)rec * rec;
-                        sa[t] += fabs((double)e);
-                        mx[t] = fmaxf(mx[t], fabsf(e));
-                        if (e != e) mx[t] = e;      // NaN propagates like torch.max
+                for (int e = 0; e < 4; ++e) mpf[e] = (64 * e + lane < nr) ? gmean[c0 + 64 * e + lane] : 0.f;
+            }
+            us = ustage_plan<ES>(c0, nr, k, nl);
+#pragma unroll
+            for (int s = 0; s < SV; ++s) {
+                const int v = tid + 64 * W * s;
+                if (v < us.nv) {
+                    const uint8_t *g = (v < us.nvh) ? gUh + us.a0h + 16ll * v : gUl + us.a0l + 16ll * (v - us.nvh);
+                    ureg[s] = *(mg_gf32x4 *)g;
+                }
+            }
+        };
+        prefetch(src, cpos);
+        int buf = 0;
+        while (true) {
+            // ---- selection of the block whose data sits in the registers
+            bool sel[4];
+            int rank[4], count;
+            if constexpr (WALK) {
+                int base = 0;
+                const int64_t room = cend - cpos;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool s = inv ? (mkpf[e] == 0u) : (mkpf[e] != 0u && mkpf[e] != 0x100u);
+                    const unsigned long long bal = __ballot(s);
+                    rank[e] = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    sel[e] = s && rank[e] < room;
+                    base += (int)__popcll(bal);
+                }
+                count = base < room ? base : (int)room;
+            } else {
+                count = (int)((src_hi - src < SVDQ_BLK_ROWS) ? (src_hi - src) : SVDQ_BLK_ROWS);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rank[e] = 64 * e + lane;
+                    sel[e] = rank[e] < count;
+                }
+            }
+            // ---- registers -> LDS
+            uint8_t *Ucur = Ubuf + buf * ubytes;
+            const UStage cur = us;
+#pragma unroll
+            for (int s = 0; s < SV; ++s) {
+                const int v = tid + 64 * W * s;
+                if (v < cur.nv) reinterpret_cast<f32x4 *>(Ucur)[v] = ureg[s];
+            }
+            if (gmean) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Xw[DG_TPW * DG_XS + 64 * e + lane] = mpf[e];
+            }
+            {
+                int slot[4];      // a selected row goes to its rank, any other to the lane's dump slot
+#pragma unroll
+                for (int e = 0; e < 4; ++e) slot[e] = sel[e] ? rank[e] : SVDQ_BLK_ROWS + lane;
+#pragma unroll
+                for (int a = 0; a < DG_TPW; ++a)      // all eight strips (those past the wave's tasks hold don't-cares)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Xw[a * DG_XS + slot[e]] = xpf[a][e];
+            }
+            if constexpr (W > 1)
+                __syncthreads();
+            else
+                lds_fence();
+            // ---- the next block's loads
+            const int64_t nsrc = src + SVDQ_BLK_ROWS, ncpos = cpos + count;
+            const bool more = nsrc < src_hi && ncpos < cend;
+            if (more) prefetch(nsrc, ncpos);
+            // ---- compute: rows 64 m + lane, two at a time
+            const T *Uh = reinterpret_cast<const T *>(Ucur) + cur.offh;
+            const T *Ul = reinterpret_cast<const T *>(Ucur + 16 * cur.nvh) + cur.offl;
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                if (128 * h >= count) break;
+                const int qa = 128 * h + lane, qb = qa + 64;
+                const bool va = qa < count, vb = qb < count;
+                const int ra = va ? qa : 0, rb = vb ? qb : 0;
+                float hi[2][DG_TPW], lo[2][DG_TPW];
+#pragma unroll
+                for (int a = 0; a < DG_TPW; ++a) hi[0][a] = hi[1][a] = lo[0][a] = lo[1][a] = 0.f;
+#pragma unroll 4
+                for (int c = 0; c < k; ++c) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cw + c * DG_TPW);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cw + c * DG_TPW + 4);
+                    const float ua = u_val(Uh, ra * k + c), ub = u_val(Uh, rb * k + c);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        hi[0][a] = fmaf(ua, c0[a], hi[0][a]);
+                        hi[0][a + 4] = fmaf(ua, c1[a], hi[0][a + 4]);
+                        hi[1][a] = fmaf(ub, c0[a], hi[1][a]);
+                        hi[1][a + 4] = fmaf(ub, c1[a], hi[1][a + 4]);
+                    }
+                }
+#pragma unroll 4
+                for (int jx = 0; jx < nl; ++jx) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cw + (k + jx) * DG_TPW);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cw + (k + jx) * DG_TPW + 4);
+                    const float ua = u_val(Ul, ra * nl + jx), ub = u_val(Ul, rb * nl + jx);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        lo[0][a] = fmaf(ua, c0[a], lo[0][a]);
+                        lo[0][a + 4] = fmaf(ua, c1[a], lo[0][a + 4]);
+                        lo[1][a] = fmaf(ub, c0[a], lo[1][a]);
+                        lo[1][a + 4] = fmaf(ub, c1[a], lo[1][a + 4]);
+                    }
+                }
+                const float ma = gmean ? Xw[DG_TPW * DG_XS + ra] : 0.f;
+                const float mb = gmean ? Xw[DG_TPW * DG_XS + rb] : 0.f;
+#pragma unroll
+                for (int a = 0; a < DG_TPW; ++a) {      // no branch on the wave's task count: strips past it are never stored
+                    {
+                        // the lane's two rows: products and their two-term sums in fp32 (each term is a rounded fp32
+                        // square -- what the reference's fp32 norms see), the running sums in fp64.  Rows past the
+                        // block's end contribute exact zeros: no divergent branch around the sums.
+                        const float xa = va ? Xw[a * DG_XS + ra] : 0.f, xb = vb ? Xw[a * DG_XS + rb] : 0.f;
+                        float ca = __fadd_rn(hi[0][a], lo[0][a]), cb = __fadd_rn(hi[1][a], lo[1][a]);
+                        if (gmean) {
+                            ca = __fadd_rn(ca, ma);
+                            cb = __fadd_rn(cb, mb);
+                        }
+                        ca = va ? ca : 0.f;
+                        cb = vb ? cb : 0.f;
+                        const float ea = __fsub_rn(xa, ca), eb = __fsub_rn(xb, cb);
+                        se[a] += (double)fmaf(eb, eb, ea * ea);
+                        sx[a] += (double)fmaf(xb, xb, xa * xa);
+                        sr[a] += (double)fmaf(cb, cb, ca * ca);
+                        sa[a] += (double)(fabsf(ea) + fabsf(eb));
+                        mx[a] = fmaxf(mx[a], fmaxf(fabsf(ea), fabsf(eb)));      // a NaN error reaches max through se (k_diag_finish)
                     }
                 }
             }
-            lds_fence();
+            if (!more) break;
+            src = nsrc;
+            cpos = ncpos;
+            buf ^= 1;
+            lds_fence();      // this wave's X strip is rewritten next
         }
     }
-    // wave reduction in a fixed order (xor butterflies), lane 0 writes the unit's partials
+    // wave reduction in a fixed order (xor butterflies), lane 0 writes the unit's partials of the wave's tasks
 #pragma unroll
-    for (int t = 0; t < NTP; ++t) {
-        double a = se[t], b = sx[t], c = sr[t], d = sa[t];
-        float q = mx[t];
+    for (int a = 0; a < DG_TPW; ++a) {
+        double qa = se[a], qb = sx[a], qc = sr[a], qd = sa[a];
+        float q = mx[a];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_xor(a, off);
-            b += __shfl_xor(b, off);
-            c += __shfl_xor(c, off);
-            d += __shfl_xor(d, off);
+            qa += __shfl_xor(qa, off);
+            qb += __shfl_xor(qb, off);
+            qc += __shfl_xor(qc, off);
+            qd += __shfl_xor(qd, off);
             const float o = __shfl_xor(q, off);
             q = (q != q) ? q : ((o != o) ? o : (o > q ? o : q));
         }
-        if (lane == 0 && t < n) {
-            DiagPart &dst = part[(size_t)blockIdx.x * n + t];
-            dst.se = a;
-            dst.sx = b;
-            dst.sr = c;
-            dst.sa = d;
+        if (lane == 0 && a < nt) {
+            DiagPart &dst = part[(size_t)blockIdx.x * n + t0 + a];
+            dst.se = qa;
+            dst.sx = qb;
+            dst.sr = qc;
+            dst.sa = qd;
             dst.mx = (double)q;
         }
     }
@@ -340,6 +723,7 @@ __global__ __launch_bounds__(64) void k_diag_finish(const SvdqParam *__restrict_
     }
     if (lane == 0) {
         double *o6 = out + ((size_t)p * n + t) * 6;
+        if (se != se) mx = se;      // an error that is NaN: torch.max propagates it (the units keep fmax of the others)
         const float en = (float)sqrt(se), on = (float)sqrt(sx);
         o6[0] = (double)en;
         o6[1] = on > 1e-10f ? (double)en / (double)on : 0.0;
@@ -385,21 +769,23 @@ extern "C" int svdq_merge_coeffs(const svdq_plan *pl, const void *small, const f
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
 
-extern "C" int svdq_merge_reconstruct(const svdq_plan *pl, const int64_t *rows_dev, const void *small, const void *basis,
-                                      const float *mean, const float *cbar, int32_t n_sets, int32_t per_param,
-                                      const float *set_share, const float *scale, const void *base_ptrs,
-                                      const void *out_ptrs, void *stream) {
-    if (int rc = merge_args_ok(pl, small, n_sets, "svdq_merge_reconstruct")) return rc;
+// the streaming launch of svdq_merge_reconstruct (mask_ptrs == NULL) and svdq_merge_masked (source walk)
+static int launch_reconstruct(const char *who, const svdq_plan *pl, const int64_t *rows_dev, const void *small,
+                              const void *basis, const float *mean, const float *cbar, int32_t n_sets,
+                              int32_t per_param, const float *set_share, const float *scale, const void *mask_ptrs,
+                              const int64_t *unit_start, const int32_t *fill, const void *base_ptrs,
+                              const void *out_ptrs, void *stream) {
+    if (int rc = merge_args_ok(pl, small, n_sets, who)) return rc;
     if (!basis || !cbar || !out_ptrs) {
-        svdq_set_error("svdq_merge_reconstruct: basis, cbar and out_ptrs are required");
+        svdq_set_error("%s: basis, cbar and out_ptrs are required", who);
         return SVDQ_EINVAL;
     }
     if (n_sets > MRG_MAX_SETS) {
-        svdq_set_error("svdq_merge_reconstruct: at most %d sets (clusters) per pass, got %d", MRG_MAX_SETS, n_sets);
+        svdq_set_error("%s: at most %d sets (clusters) per pass, got %d", who, MRG_MAX_SETS, n_sets);
         return SVDQ_EUNSUPPORTED;
     }
     if (n_sets > 1 && !set_share) {
-        svdq_set_error("svdq_merge_reconstruct: set_share is required when n_sets > 1");
+        svdq_set_error("%s: set_share is required when n_sets > 1", who);
         return SVDQ_EINVAL;
     }
     const svdq_small_layout &L = pl->small;
@@ -407,14 +793,24 @@ extern "C" int svdq_merge_reconstruct(const svdq_plan *pl, const int64_t *rows_d
     auto kk = reinterpret_cast<const int32_t *>(sm + L.k_off), rr = reinterpret_cast<const int32_t *>(sm + L.r_off);
     auto bp = reinterpret_cast<const float *const *>(base_ptrs);
     auto op = reinterpret_cast<float *const *>(out_ptrs);
+    auto mp = reinterpret_cast<const uint8_t *const *>(mask_ptrs);
     hipStream_t st = (hipStream_t)stream;
     const int ns = n_sets == 1 ? 1 : (n_sets == 2 ? 2 : (n_sets <= 4 ? 4 : 8));
-    const size_t lds = (size_t)SVDQ_BLK_ROWS * pl->n_tasks * (pl->cfg.fp16 ? 2 : 4) + (size_t)(ns * pl->n_tasks + ns) * 4;
+    const size_t lds = (size_t)SVDQ_BLK_ROWS * pl->n_tasks * (pl->cfg.fp16 ? 2 : 4) + (mp ? 64 : 0) +
+                       (size_t)(ns * pl->n_tasks + ns) * 4;
     const uint8_t *bs = reinterpret_cast<const uint8_t *>(basis);
     const float *mn = pl->cfg.center ? mean : nullptr;
 #define SVDQ_MRG_LAUNCH(F16, NS_)                                                                                      \
-    hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params, pl->d_units, \
-                       rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share, scale, bp, op)
+    do {                                                                                                               \
+        if (mp)                                                                                                        \
+            hipLaunchKernelGGL((k_merge_expand<F16, NS_>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,          \
+                               pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
+                               scale, mp, unit_start, fill, bp, op);                                                   \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,     \
+                               pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
+                               scale, bp, op);                                                                         \
+    } while (0)
     if (pl->cfg.fp16) {
         switch (ns) {
             case 1: SVDQ_MRG_LAUNCH(true, 1); break;
@@ -432,6 +828,29 @@ extern "C" int svdq_merge_reconstruct(const svdq_plan *pl, const int64_t *rows_d
     }
 #undef SVDQ_MRG_LAUNCH
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+extern "C" int svdq_merge_reconstruct(const svdq_plan *pl, const int64_t *rows_dev, const void *small, const void *basis,
+                                      const float *mean, const float *cbar, int32_t n_sets, int32_t per_param,
+                                      const float *set_share, const float *scale, const void *base_ptrs,
+                                      const void *out_ptrs, void *stream) {
+    return launch_reconstruct("svdq_merge_reconstruct", pl, rows_dev, small, basis, mean, cbar, n_sets, per_param,
+                              set_share, scale, nullptr, nullptr, nullptr, base_ptrs, out_ptrs, stream);
+}
+
+extern "C" int svdq_merge_masked(const svdq_plan *pl, const int64_t *rows_dev, const void *small, const void *basis,
+                                 const float *mean, const float *weights, const int32_t *order, int32_t n_sets,
+                                 int32_t per_param, const float *set_share, const float *scale, const void *mask_ptrs,
+                                 const int64_t *unit_start, const int32_t *fill, const void *base_ptrs,
+                                 const void *out_ptrs, void *work, void *stream) {
+    if (!work || !mask_ptrs || !unit_start || !rows_dev) {
+        svdq_set_error("svdq_merge_masked: work, mask_ptrs, unit_start and rows_dev are required");
+        return SVDQ_EINVAL;
+    }
+    float *cbar = reinterpret_cast<float *>(work);
+    if (int rc = svdq_merge_coeffs(pl, small, weights, order, n_sets, per_param, cbar, stream)) return rc;
+    return launch_reconstruct("svdq_merge_masked", pl, rows_dev, small, basis, mean, cbar, n_sets, per_param, set_share,
+                              scale, mask_ptrs, unit_start, fill, base_ptrs, out_ptrs, stream);
 }
 
 extern "C" int svdq_merge(const svdq_plan *pl, const int64_t *rows_dev, const void *small, const void *basis,
@@ -461,24 +880,36 @@ __global__ void k_one_hot(int n, float *w) {
     if (e < n * n) w[e] = (e / n == e % n) ? 1.f : -1.f;
 }
 
-template <int NTP>
-static void launch_diag(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const int32_t *kk,
-                        const int32_t *rr, const uint8_t *basis, const float *mean, int add_mean, const float *ctask,
-                        DiagPart *part, hipStream_t st) {
+template <int W>
+static void launch_diag(const svdq_plan *pl, const void *ptrs, const void *mask_ptrs, const int64_t *unit_start,
+                        const int64_t *rows_dev, const int32_t *kk, const int32_t *rr, const uint8_t *basis,
+                        const float *mean, int add_mean, const float *ctask, DiagPart *part, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
-    if (pl->cfg.fp16)
-        hipLaunchKernelGGL((k_diag<NTP, true>), dim3(pl->n_units), dim3(64), 0, st, pl->d_params, pl->d_units, pp,
-                           rows_dev, pl->n_tasks, kk, rr, basis, mean, add_mean, ctask, part);
-    else
-        hipLaunchKernelGGL((k_diag<NTP, false>), dim3(pl->n_units), dim3(64), 0, st, pl->d_params, pl->d_units, pp,
-                           rows_dev, pl->n_tasks, kk, rr, basis, mean, add_mean, ctask, part);
+    auto mp = reinterpret_cast<const uint8_t *const *>(mask_ptrs);
+    const int n = pl->n_tasks, es = pl->cfg.fp16 ? 2 : 4;
+    const size_t lds = 2 * (size_t)svdq_align_up((int64_t)SVDQ_BLK_ROWS * n * es + 64, 16) +
+                       (size_t)W * n * DG_TPW * 4 + (size_t)W * (DG_TPW + 1) * DG_XS * 4;
+#define SVDQ_DIAG_LAUNCH(F16, WALK_)                                                                                   \
+    do {                                                                                                               \
+        if (lds > 65536)                                                                                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<W, F16, WALK_>),                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        hipLaunchKernelGGL((k_diag<W, F16, WALK_>), dim3(pl->n_units), dim3(64 * W), lds, st, pl->d_params,             \
+                           pl->d_units, pp, mp, unit_start, rows_dev, n, kk, rr, basis, mean, add_mean, ctask, part);  \
+    } while (0)
+    if (pl->cfg.fp16) {
+        if (mp) SVDQ_DIAG_LAUNCH(true, true); else SVDQ_DIAG_LAUNCH(true, false);
+    } else {
+        if (mp) SVDQ_DIAG_LAUNCH(false, true); else SVDQ_DIAG_LAUNCH(false, false);
+    }
+#undef SVDQ_DIAG_LAUNCH
 }
 
-extern "C" int svdq_diagnostics(const svdq_plan *pl, const void *delta_ptrs, const int64_t *rows_dev, const void *small,
-                                const void *basis, const float *mean, int32_t add_mean, double *out, void *work,
-                                void *stream) {
+static int run_diagnostics(const char *who, const svdq_plan *pl, const void *delta_ptrs, const void *mask_ptrs,
+                           const int64_t *unit_start, const int64_t *rows_dev, const void *small, const void *basis,
+                           const float *mean, int32_t add_mean, double *out, void *work, void *stream) {
     if (!pl || !delta_ptrs || !small || !basis || !out || !work) {
-        svdq_set_error("svdq_diagnostics: bad argument");
+        svdq_set_error("%s: bad argument", who);
         return SVDQ_EINVAL;
     }
     const int64_t n = pl->n_tasks;
@@ -495,16 +926,34 @@ extern "C" int svdq_diagnostics(const svdq_plan *pl, const void *delta_ptrs, con
     const uint8_t *sm = reinterpret_cast<const uint8_t *>(small);
     auto kk = reinterpret_cast<const int32_t *>(sm + L.k_off), rr = reinterpret_cast<const int32_t *>(sm + L.r_off);
     auto bs = reinterpret_cast<const uint8_t *>(basis);
-#define SVDQ_DIAG_CASE(N_) \
-    case N_: launch_diag<N_>(pl, delta_ptrs, rows_dev, kk, rr, bs, mean, add_mean, ctask, part, st); break
-    switch (pl->ntp) {
-        SVDQ_DIAG_CASE(4); SVDQ_DIAG_CASE(8); SVDQ_DIAG_CASE(12); SVDQ_DIAG_CASE(16);
-        SVDQ_DIAG_CASE(20); SVDQ_DIAG_CASE(24); SVDQ_DIAG_CASE(28); SVDQ_DIAG_CASE(32);
+#define SVDQ_DIAG_CASE(W_) \
+    case W_: launch_diag<W_>(pl, delta_ptrs, mask_ptrs, unit_start, rows_dev, kk, rr, bs, mean, add_mean, ctask, part, st); break
+    switch ((int)((n + DG_TPW - 1) / DG_TPW)) {
+        SVDQ_DIAG_CASE(1); SVDQ_DIAG_CASE(2); SVDQ_DIAG_CASE(3); SVDQ_DIAG_CASE(4);
         default:
-            svdq_set_error("unsupported padded task count %d", pl->ntp);
+            svdq_set_error("%s: unsupported task count %d", who, (int)n);
             return SVDQ_EUNSUPPORTED;
     }
 #undef SVDQ_DIAG_CASE
     hipLaunchKernelGGL(k_diag_finish, dim3(pl->n_params, (int)n), dim3(64), 0, st, pl->d_params, rows_dev, (int)n, part, out);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
+}
+
+extern "C" int svdq_diagnostics(const svdq_plan *pl, const void *delta_ptrs, const int64_t *rows_dev, const void *small,
+                                const void *basis, const float *mean, int32_t add_mean, double *out, void *work,
+                                void *stream) {
+    return run_diagnostics("svdq_diagnostics", pl, delta_ptrs, nullptr, nullptr, rows_dev, small, basis, mean, add_mean,
+                           out, work, stream);
+}
+
+extern "C" int svdq_diagnostics_masked(const svdq_plan *pl, const void *delta_ptrs, const void *mask_ptrs,
+                                       const int64_t *unit_start, const int64_t *rows_dev, const void *small,
+                                       const void *basis, const float *mean, int32_t add_mean, double *out, void *work,
+                                       void *stream) {
+    if (!mask_ptrs || !unit_start || !rows_dev) {
+        svdq_set_error("svdq_diagnostics_masked: mask_ptrs, unit_start and rows_dev are required");
+        return SVDQ_EINVAL;
+    }
+    return run_diagnostics("svdq_diagnostics_masked", pl, delta_ptrs, mask_ptrs, unit_start, rows_dev, small, basis, mean,
+                           add_mean, out, work, stream);
 }

@@ -114,22 +114,31 @@ def compute_parameter_diagnostics(param_name: str, task_vectors: Dict[str, Dict[
 
 
 def _batched_errors(task_vectors, compressed_all, bases, masks) -> Dict[str, Dict]:
-    """compute_parameter_diagnostics for every unmasked parameter whose artifacts still live in the buffers of a fused
-    run: ONE pass over U and the N deltas per plan (svdq_diagnostics: all N error tuples of a parameter from a single
-    read of its basis) and one small D2H copy, instead of a payload upload + dequantize + fused-error launch per
-    (parameter, task).  Same dictionaries; parameters it cannot take (masked, foreign artifacts, other tensors than
-    the run compressed) are left to the per-parameter route."""
-    from .merge import _batched_entry
+    """compute_parameter_diagnostics for every parameter whose artifacts still live in the buffers of a fused run: ONE
+    pass over U and the N deltas per plan (svdq_diagnostics: all N error tuples of a parameter from a single read of
+    its basis; masked parameters: svdq_diagnostics_masked, the selection made inside the pass) and one small D2H
+    copy, instead of a mask compaction + payload upload + dequantize + fused-error launch per (parameter, task).
+    Same dictionaries; parameters it cannot take (foreign artifacts, another mask or other tensors than the run
+    compressed) are left to the per-parameter route."""
+    from .merge import _batched_entry, _mask_identity
     plans = {}
     for name in bases.keys():
-        if name not in compressed_all or masks.get(name) is not None:
+        if name not in compressed_all:
             continue
         got = _batched_entry(name, compressed_all, bases)
         if got is None:
             continue
         batch, i, meta = got
-        if getattr(batch, "mode", None) != "plain" or getattr(batch, "from_base", True):
+        mode = getattr(batch, "mode", None)
+        if mode not in ("plain", "walk", "gather") or getattr(batch, "from_base", True):
             continue
+        mask = masks.get(name)
+        if mode == "plain":
+            if mask is not None:
+                continue
+        elif (mask is None or batch.unit_start is None
+              or getattr(batch, "mask_ident", {}).get(name) != _mask_identity(mask)):
+            continue      # the selection is made with the mask the run compressed with
         # the error is measured against the tensors the CALLER passes: they must be the ones the plan still points at
         kept = batch.plan._keep[i] if batch.plan._keep is not None else None
         tasks_i = batch.task_names[i]
@@ -142,7 +151,11 @@ def _batched_errors(task_vectors, compressed_all, bases, masks) -> Dict[str, Dic
     for batch, items in plans.values():
         plan, small = batch.plan, batch.small
         with torch.cuda.device(plan.device):
-            res = plan.diagnostics(batch.table, batch.rows_dev).cpu().numpy()      # [P, N, 6]
+            if batch.mode == "plain":
+                res = plan.diagnostics(batch.table, batch.rows_dev)
+            else:
+                res = plan.diagnostics_masked(batch.table, batch.mask_table, batch.unit_start, batch.rows_dev)
+            res = res.cpu().numpy()      # [P, N, 6]
         for name, i, meta in items:
             tasks_i = batch.task_names[i]
             pos = {t: j for j, t in enumerate(tasks_i)}
@@ -151,8 +164,12 @@ def _batched_errors(task_vectors, compressed_all, bases, masks) -> Dict[str, Dic
                     "reconstruction_errors": {}, "compression_ratios": {}}
             if name in task_vectors[first]:
                 diag["original_shape"] = list(task_vectors[first][name].shape)
-            diag["masked_size"] = np.prod(diag["original_shape"])
             k, r, rows = int(small.k[i]), int(small.r[i]), int(small.rows[i])
+            if batch.mode == "plain":
+                diag["masked_size"] = np.prod(diag["original_shape"])
+            else:      # mask.sum() / (~mask).sum() (diagnostics.py:168-169): the counts the run kept on the device
+                diag["masked_size"] = rows
+                diag["unmasked_size"] = int(plan.rows[i]) - rows
             diag["basis"] = {"k": k, "D": rows, "N": plan.N, "energy_retained": float(small.energy[i])}
             nl, bits, stages = r - k, plan.bits_of(i), plan.S
             ratio = (nl * 4) / max(nl * bits / 8 * stages + 8 * stages, 1)      # estimate_compression_ratio, rtvq.py:142-161

@@ -89,22 +89,21 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
             if not walk_sig or (include_noise and not walk_noise):
                 it_, if_, _, _ = ms.indices(mask_list, want_false=include_noise and not walk_noise)
             keep.append((ms, it_, if_))
-            for q, (name, present, deltas, _) in enumerate(items):
+            for q, (name, present, deltas, mask_q) in enumerate(items):
                 vs = [prepare_vector(d, dev) for d in deltas]
+                ident = (mask_q.data_ptr(), mask_q.numel(), str(mask_q.device), mask_q.dtype)
                 bvec = prepare_vector(base_state[name], dev) if base_state is not None else None
                 e = {"name": name, "region": "masked", "tasks": present, "vectors": vs, "count": ct[q:q + 1],
                      "upper": vs[0].numel(), "min": min_size, "base": bvec}
-                if walk_sig:
-                    e.update(ms=ms, q=q, inv=False)
-                else:
+                e.update(ms=ms, q=q, inv=False, mask_ident=ident)
+                if not walk_sig:
                     e["index"] = it_[q]
                 groups.setdefault((n_present, "walk" if walk_sig else "gather"), []).append(e)
                 if include_noise:
                     e = {"name": name, "region": "noise", "tasks": present, "vectors": vs, "count": cf[q:q + 1],
                          "upper": vs[0].numel(), "min": 1, "gate": ct[q:q + 1], "base": bvec}
-                    if walk_noise:
-                        e.update(ms=ms, q=q, inv=True)
-                    else:
+                    e.update(ms=ms, q=q, inv=True, mask_ident=ident)
+                    if not walk_noise:
                         e["index"] = if_[q]
                     groups.setdefault((n_present, "walk" if walk_noise else "gather"), []).append(e)
         order = {n: i for i, n in enumerate(names)}
@@ -141,11 +140,15 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
             if base_state is not None:
                 btab = torch.tensor([e["base"].data_ptr() for e in entries], dtype=torch.int64).to(dev)
                 keep.append([e["base"] for e in entries])
-            if mode == "walk":
+            mtab = us = None
+            if mode in ("walk", "gather"):
+                # one source start per work unit: the walk mode's way to the rows, and what the batched consumers
+                # (svdq_merge_masked / svdq_diagnostics_masked) put the merged rows back with, whichever mode compressed
                 ms = entries[0]["ms"]
                 mtab = torch.tensor([ms._s["mb"][e["q"]].data_ptr() for e in entries], dtype=torch.int64).to(dev)
                 us = ms.unit_starts(plan, rows_dev, entry_map=[(e["q"], e["inv"]) for e in entries], mask_table=mtab)
                 keep.append((mtab, us))
+            if mode == "walk":
                 if btab is not None:
                     plan.run_masked_from_base(table, btab, mtab, us, rows_dev)
                 else:
@@ -166,6 +169,8 @@ def build_bases(task_vectors: Dict[str, Dict[str, torch.Tensor]], combined_masks
             batch.keep = keep
             # for the batched consumers (svdq_diagnostics reads the deltas again): what the run was launched with
             batch.mode, batch.table, batch.rows_dev = mode, table, rows_dev
+            batch.mask_table, batch.unit_start = mtab, us
+            batch.mask_ident = {e["name"]: e["mask_ident"] for e in entries if "mask_ident" in e}
             batch.from_base = base_state is not None
             for i, e in enumerate(entries):
                 slot = bases.setdefault(e["name"], {"masked": None, "noise": None})

@@ -146,20 +146,25 @@ def _task_weights(have, tasks_i, members, weights):
     return row, True
 
 
+def _mask_identity(mask) -> Optional[tuple]:
+    return None if mask is None else (mask.data_ptr(), mask.numel(), str(mask.device), mask.dtype)
+
+
 def _merge_batched(names, compressed_all, bases, masks, sets, original_shapes, config, device):
     """merge_all_parameters / merge_with_clustering for the parameters whose artifacts still live in the buffers of a
     fused run: per plan ONE coefficient kernel + ONE streaming reconstruction (svdq_merge) instead of, per parameter
-    and task, a host->device copy of the payloads, a dequantize launch, a stack/sum and a reconstruct launch.
+    and task, a host->device copy of the payloads, a dequantize launch, a stack/sum and a reconstruct launch.  Masked
+    parameters: the same two launches per plan with reconstruct_from_masked inside the streaming one
+    (svdq_merge_masked: signal and noise regions write their own rows of the full tensor).
     ``sets``: [(weights dict, members or None)] and, for more than one set, their shares (device tensor).
     Returns {name: merged delta} for the names it could take; the rest goes the per-parameter way."""
     import numpy as np
-    from .mask_loader import reconstruct_from_masked
     set_list, shares = sets
     S = len(set_list)
     if S > 8:
         return {}
     dev = resolve_device(device)
-    jobs = {}      # id(plan) -> (plan, {entry index: (name, region, meta)})
+    jobs = {}      # id(plan) -> (plan batch, {entry index: (name, region, meta)})
     for name in names:
         got = _batched_entry(name, compressed_all, bases)
         if got is None:
@@ -169,22 +174,45 @@ def _merge_batched(names, compressed_all, bases, masks, sets, original_shapes, c
         if config.svd_include_noise and meta["noise"] is not None:
             nb, j = meta["noise"]
             jobs.setdefault(id(nb.plan), (nb, {}))[1][j] = (name, "noise", meta)
-    pieces = {}    # name -> {"masked": tensor, "noise": tensor}
+    # the per-plan tables, and which (parameter, region) pairs have something to merge
+    tables, live = {}, {}
+    for key, (batch, entries) in jobs.items():
+        plan, small = batch.plan, batch.small
+        P, N = plan.P, plan.N
+        wt = np.full((P, S, N), -1.0, dtype=np.float32)
+        order = np.tile(np.arange(N, dtype=np.int32), (P, 1))
+        scale = np.ones(P, dtype=np.float32)
+        share_ok = np.zeros((P, S), dtype=bool)
+        for i, (name, region, meta) in entries.items():
+            tasks_i = batch.task_names[i]
+            order[i] = np.argsort(np.array(tasks_i, dtype=object), kind="stable").astype(np.int32)
+            for s_, (w, members) in enumerate(set_list):
+                wt[i, s_], share_ok[i, s_] = _task_weights(meta["have"], tasks_i, members, w)
+            if region == "noise":
+                scale[i] = np.float32(config.svd_noise_shrink)
+            if int(small.rows[i]) > 0 and share_ok[i].any():
+                live.setdefault(name, {})[region] = (key, i)
+        tables[key] = (wt, order, scale, share_ok)
+    # masked parameters go through the fused scatter when the caller's mask is the one the run compressed with
+    full, fused = {}, set()
+    for name, regs in live.items():
+        if "masked" not in regs:
+            continue
+        batch = jobs[regs["masked"][0]][0]
+        if getattr(batch, "mode", "plain") == "plain":
+            continue
+        ident = getattr(batch, "mask_ident", {}).get(name)
+        nb = jobs[regs["noise"][0]][0] if "noise" in regs else None
+        if (ident is None or ident != _mask_identity(masks.get(name)) or batch.unit_start is None
+                or (nb is not None and (nb.unit_start is None or getattr(nb, "mask_ident", {}).get(name) != ident))):
+            continue
+        fused.add(name)
+    pieces = {}    # name -> {"masked": tensor, "noise": tensor} (compacted rows; the unfused way)
     with torch.cuda.device(dev):
-        for batch, entries in jobs.values():
+        for key, (batch, entries) in jobs.items():
             plan, small = batch.plan, batch.small
-            P, N = plan.P, plan.N
-            wt = np.full((P, S, N), -1.0, dtype=np.float32)
-            order = np.tile(np.arange(N, dtype=np.int32), (P, 1))
-            scale = np.ones(P, dtype=np.float32)
-            share_ok = np.zeros((P, S), dtype=bool)
-            for i, (name, region, meta) in entries.items():
-                tasks_i = batch.task_names[i]
-                order[i] = np.argsort(np.array(tasks_i, dtype=object), kind="stable").astype(np.int32)
-                for s_, (w, members) in enumerate(set_list):
-                    wt[i, s_], share_ok[i, s_] = _task_weights(meta["have"], tasks_i, members, w)
-                if region == "noise":
-                    scale[i] = np.float32(config.svd_noise_shrink)
+            P = plan.P
+            wt, order, scale, share_ok = tables[key]
             wt_d = torch.from_numpy(wt).to(plan.device)
             ord_d = torch.from_numpy(order).to(plan.device)
             sc_d = torch.from_numpy(scale).to(plan.device)
@@ -198,12 +226,26 @@ def _merge_batched(names, compressed_all, bases, masks, sets, original_shapes, c
                     tot = tot + sh[:, s_]
                 sh_d = torch.where(ok, sh / tot.view(P, 1), torch.full((), -1.0, device=plan.device)).contiguous()
             rows_dev = plan.small[plan.layout.rows_off:plan.layout.rows_off + 8 * P].view(torch.int64)
-            buf, offs = plan.merge(wt_d, order=ord_d, set_share=sh_d, scale=sc_d, rows_dev=rows_dev)
-            for i, (name, region, meta) in entries.items():
-                rows = int(small.rows[i])
-                if rows > 0 and share_ok[i].any():
-                    pieces.setdefault(name, {})[region] = buf[offs[i]:offs[i] + rows]
-    out = {}
+            mine = {i: e for i, e in entries.items() if live.get(e[0], {}).get(e[1]) == (key, i)}
+            take = {i: e for i, e in mine.items() if e[0] in fused}
+            if take:
+                out_tab = np.zeros(P, dtype=np.int64)
+                fill = np.zeros(P, dtype=np.int32)
+                for i, (name, region, meta) in take.items():
+                    if name not in full:
+                        full[name] = torch.empty(plan.rows[i], dtype=torch.float32, device=plan.device)
+                    out_tab[i] = full[name].data_ptr()
+                    fill[i] = int(region == "masked" and "noise" not in live[name])
+                plan.merge_masked(wt_d, batch.mask_table, batch.unit_start, rows_dev,
+                                  torch.from_numpy(out_tab).to(plan.device), order=ord_d, set_share=sh_d, scale=sc_d,
+                                  fill=torch.from_numpy(fill).to(plan.device))
+            if len(take) < len(mine):
+                buf, offs = plan.merge(wt_d, order=ord_d, set_share=sh_d, scale=sc_d, rows_dev=rows_dev)
+                for i, (name, region, meta) in mine.items():
+                    if i not in take:
+                        pieces.setdefault(name, {})[region] = buf[offs[i]:offs[i] + int(small.rows[i])]
+    from .mask_loader import reconstruct_from_masked
+    out = {name: t.view(original_shapes[name]) for name, t in full.items()}
     for name, pc in pieces.items():
         if "masked" not in pc:
             continue

@@ -315,6 +315,37 @@ class CompressPlan:
                                       _ptr(base_table), _ptr(out_table), _ptr(work), _stream_ptr()), "svdq_merge")
         return (buf, offs) if own else None
 
+    def merge_masked(self, weights: torch.Tensor, mask_table: torch.Tensor, unit_start: torch.Tensor,
+                     rows_dev: torch.Tensor, out_table: torch.Tensor, order: Optional[torch.Tensor] = None,
+                     set_share: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+                     fill: Optional[torch.Tensor] = None, base_table: Optional[torch.Tensor] = None) -> None:
+        """``merge`` for a plan of masked regions, with reconstruct_from_masked inside the streaming launch
+        (svdq_merge_masked): ``out_table`` int64 [P] names FULL tensors (0 = skip the entry), ``mask_table`` /
+        ``unit_start`` are what run_masked took (MaskSet.unit_starts), ``fill`` int32 [P]: 1 = the entry also writes the
+        rows its region does not select (0, + base) -- a signal region that has no noise region."""
+        per_param = 1 if weights.dim() == 3 else 0
+        n_sets = int(weights.shape[-2])
+        work = getattr(self, "_merge_work", None)
+        need = int(self.lib.svdq_merge_work_bytes(self._h, n_sets))
+        if work is None or work.numel() < need:
+            work = self._merge_work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        nat.check(self.lib.svdq_merge_masked(self._h, _ptr(rows_dev), _ptr(self.small), _ptr(self.basis), _ptr(self.mean),
+                                             _ptr(weights), _ptr(order), n_sets, per_param, _ptr(set_share), _ptr(scale),
+                                             _ptr(mask_table), _ptr(unit_start), _ptr(fill), _ptr(base_table),
+                                             _ptr(out_table), _ptr(work), _stream_ptr()), "svdq_merge_masked")
+
+    def diagnostics_masked(self, table, mask_table: torch.Tensor, unit_start: torch.Tensor, rows_dev: torch.Tensor,
+                           add_mean: bool = False) -> torch.Tensor:
+        """``diagnostics`` for a plan of masked regions: ``table`` names the UNMASKED task deltas, the selection
+        (apply_mask_to_tensor, diagnostics.py:186-199) happens inside the pass (svdq_diagnostics_masked)."""
+        out = torch.empty((self.P, self.N, 6), dtype=torch.float64, device=self.device)
+        work = torch.empty(int(self.lib.svdq_diagnostics_work_bytes(self._h)), dtype=torch.uint8, device=self.device)
+        nat.check(self.lib.svdq_diagnostics_masked(self._h, _ptr(table), _ptr(mask_table), _ptr(unit_start),
+                                                   _ptr(rows_dev), _ptr(self.small), _ptr(self.basis), _ptr(self.mean),
+                                                   int(bool(add_mean)), _ptr(out), _ptr(work), _stream_ptr()),
+                  "svdq_diagnostics_masked")
+        return out
+
     def diagnostics(self, table, rows_dev: Optional[torch.Tensor] = None, add_mean: bool = False) -> torch.Tensor:
         """[P, N, 6] float64 (device): absolute_error, relative_error, max_absolute_error, mean_absolute_error,
         original_norm, reconstructed_norm of every (parameter, task) from one pass over U and the N deltas

@@ -323,9 +323,25 @@ def test_batched_merge_is_the_per_parameter_merge(sq, with_masks, include_noise)
     bases, comp = sq.run_basis_and_compress(tv, masks, cfg, "cuda")
     plain = {n: {t: dict(a) if a is not None else None for t, a in v.items()} for n, v in comp.items()}   # no batch handle
     fast = sq.merge_all_parameters(comp, bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
-    from svdq_amd import merge as mg
-    assert len(mg._merge_batched(sorted(comp), comp, bases, masks, ([(weights, None)], None), shapes, cfg, "cuda")) \
-        == len(comp)                                                         # every parameter took the batched route
+    from svdq_amd import merge as mg, mask_loader as mlo, pipeline as pipe
+    calls = {"fused": 0, "expand": 0}
+    orig_mm, orig_rm = pipe.CompressPlan.merge_masked, mlo.reconstruct_from_masked
+
+    def spy_mm(self, *a, **kw):
+        calls["fused"] += 1
+        return orig_mm(self, *a, **kw)
+
+    def spy_rm(*a, **kw):
+        calls["expand"] += 1
+        return orig_rm(*a, **kw)
+    pipe.CompressPlan.merge_masked, mlo.reconstruct_from_masked = spy_mm, spy_rm
+    try:
+        assert len(mg._merge_batched(sorted(comp), comp, bases, masks, ([(weights, None)], None), shapes, cfg, "cuda")) \
+            == len(comp)                                                     # every parameter took the batched route
+    finally:
+        pipe.CompressPlan.merge_masked, mlo.reconstruct_from_masked = orig_mm, orig_rm
+    # masked parameters: scattered inside the streaming launch (signal plan, and the noise plan when there is one)
+    assert calls == {"fused": (2 if include_noise else 1) if with_masks else 0, "expand": 0}
     slow = sq.merge_all_parameters(plain, bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
     assert sorted(fast) == sorted(slow) == sorted(shapes)
     for n in shapes:
@@ -344,25 +360,29 @@ def test_batched_merge_is_the_per_parameter_merge(sq, with_masks, include_noise)
         assert _same_bits(cf[n], cs[n]), n
 
 
-def test_batched_diagnostics_match_per_parameter(sq):
-    """compute_all_diagnostics through svdq_diagnostics (one pass over U and the N deltas per plan) against the
-    per-(parameter, task) fused-error route: same dictionaries, numbers equal to the last digits of the fp64 sums."""
+@pytest.mark.parametrize("with_masks", [False, True])
+def test_batched_diagnostics_match_per_parameter(sq, with_masks):
+    """compute_all_diagnostics through svdq_diagnostics (one pass over U and the N deltas per plan; masked parameters:
+    svdq_diagnostics_masked, the selection made inside the pass) against the per-(parameter, task) fused-error route:
+    same dictionaries, numbers equal to the last digits of the fp64 sums."""
     from oracle import svd_hybrid_oracle as orc
     from svdq_amd import diagnostics as dg
     tasks = ["t3", "t1", "t2", "t0"]
-    tv, masks, shapes = _model_like(orc, tasks, False)
+    tv, masks, shapes = _model_like(orc, tasks, with_masks)
     tv = {t: {n: v.flatten() for n, v in d.items()} for t, d in tv.items()}      # resident flat tensors: the plan keeps them
+    masks = {n: m.flatten() for n, m in masks.items()}
     cfg = sq.SVDHybridConfig(tasks=tasks, svd_energy_threshold=0.9, svd_max_rank=2, svd_low_bits=4, svd_rtvq_stages=2)
-    bases, comp = sq.run_basis_and_compress(tv, None, cfg, "cuda")
-    assert len(dg._batched_errors(tv, comp, bases, {})) == len(shapes)
-    fast = sq.compute_all_diagnostics(tv, comp, bases, {}, cfg, device="cuda")
+    bases, comp = sq.run_basis_and_compress(tv, masks or None, cfg, "cuda")
+    assert len(dg._batched_errors(tv, comp, bases, masks)) == len(shapes)
+    fast = sq.compute_all_diagnostics(tv, comp, bases, masks, cfg, device="cuda")
     plain = {n: {t: dict(a) for t, a in v.items()} for n, v in comp.items()}
-    slow = sq.compute_all_diagnostics(tv, plain, bases, {}, cfg, device="cuda")
+    slow = sq.compute_all_diagnostics(tv, plain, bases, masks, cfg, device="cuda")
     assert list(fast["per_parameter"]) == list(slow["per_parameter"])
     for n in shapes:
         f, s = fast["per_parameter"][n], slow["per_parameter"][n]
         assert list(f.keys()) == list(s.keys()) and f["basis"] == s["basis"] and f["original_shape"] == s["original_shape"]
         assert int(f["masked_size"]) == int(s["masked_size"]) and f["compression_ratios"] == s["compression_ratios"]
+        assert int(f["unmasked_size"]) == int(s["unmasked_size"])
         assert list(f["reconstruction_errors"]) == list(s["reconstruction_errors"]) == tasks
         for t in tasks:
             for key, v in s["reconstruction_errors"][t].items():
