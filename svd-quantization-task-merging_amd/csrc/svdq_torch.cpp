@@ -21,6 +21,10 @@
 //   recon_error(Tensor U_high, Tensor U_low, Tensor coef, Tensor? mean, Tensor orig) -> Tensor      (float64 [6])
 //   merge(Tensor small, Tensor basis, Tensor mean, int[] rows, int n_tasks, <settings>, Tensor weights, Tensor[] base)
 //       -> Tensor[]                                            svdq_merge on the buffers `compress` returned
+//   merge_masked(Tensor small, Tensor basis, Tensor mean, Tensor[] masks, int n_tasks, <settings>, Tensor weights,
+//       Tensor[] base) -> Tensor[]                             svdq_merge_masked: full-size tensors, mask scatter fused
+//   diagnostics(Tensor[] deltas, Tensor[] masks, Tensor small, Tensor basis, Tensor mean, int n_tasks, <settings>,
+//       bool add_mean) -> Tensor                               float64 [P, n_tasks, 6]; masks empty = unmasked
 //   ingest(Tensor base, Tensor[] finetuned) -> Tensor[]
 //   task_gram(Tensor[] deltas, int n_tasks) -> Tensor
 //   plan_cache_size() -> int                                  plans kept by compress (for tests)
@@ -470,6 +474,144 @@ std::vector<at::Tensor> merge(const at::Tensor &small, const at::Tensor &basis, 
     return outs;
 }
 
+// the mask tables both masked consumers need: combined mask bytes, their counts and one source start per work unit
+struct MaskWalk {
+    std::vector<at::Tensor> mb;
+    at::Tensor mtab, ct, us, work;
+};
+static MaskWalk mask_walk(svdq_maskset *ms, const Plan &plan, at::TensorList masks, const std::vector<int64_t> &rows,
+                          const c10::Device &dev, void *stream, const char *what) {
+    MaskWalk m;
+    const int64_t P = (int64_t)rows.size();
+    TORCH_CHECK_VALUE((int64_t)masks.size() == P, what, ": one combined mask per parameter");
+    for (int64_t p = 0; p < P; ++p) {
+        TORCH_CHECK_VALUE(masks[p].device() == dev, what, ": all tensors must live on one device");
+        TORCH_CHECK_VALUE(masks[p].numel() == rows[p], "Shape mismatch: tensor vs mask for parameter ", p);
+        m.mb.push_back(mask_bytes(masks[p]));
+    }
+    m.work = bytes_on(dev, svdq_maskset_work_bytes(ms));
+    m.ct = at::zeros({P}, at::TensorOptions().dtype(at::kLong).device(dev));
+    m.mtab = table_of(m.mb, dev);
+    m.us = at::empty({plan.sizes.n_units}, at::TensorOptions().dtype(at::kLong).device(dev));
+    int rc = svdq_maskset_count_scan(ms, m.mtab.data_ptr(), m.ct.data_ptr<int64_t>(), nullptr, m.work.data_ptr(), stream);
+    if (rc == SVDQ_OK)
+        rc = svdq_maskset_unit_starts(ms, plan.h, m.mtab.data_ptr(), nullptr, m.ct.data_ptr<int64_t>(), m.work.data_ptr(),
+                                      m.us.data_ptr<int64_t>(), stream);
+    check(rc, what);
+    return m;
+}
+
+// svdq_merge_masked on the buffers `compress_masked` / `compress_gather` returned for the same tensors, masks and
+// settings: the merged delta of every parameter at FULL size (zeros where the mask is clear), + base when given
+std::vector<at::Tensor> merge_masked(const at::Tensor &small, const at::Tensor &basis, const at::Tensor &mean,
+                                     at::TensorList masks, int64_t n_tasks, double energy, int64_t max_rank, bool center,
+                                     bool fp16, int64_t bits, int64_t stages, const at::Tensor &weights,
+                                     at::TensorList base) {
+    TORCH_CHECK(small.is_cuda() && basis.is_cuda(), "svdq operators take device tensors");
+    const c10::Device dev = small.device();
+    c10::DeviceGuard guard(dev);
+    void *stream = stream_of(dev);
+    const int64_t P = (int64_t)masks.size();
+    TORCH_CHECK_VALUE(P >= 1, "Empty mask list");
+    std::vector<int64_t> rows;
+    for (int64_t p = 0; p < P; ++p) rows.push_back(masks[p].numel());
+    TORCH_CHECK_VALUE(base.empty() || (int64_t)base.size() == P, "merge_masked: one base tensor per parameter, or none");
+    at::Tensor w = weights.to(dev, at::kFloat).contiguous();
+    TORCH_CHECK_VALUE((w.dim() == 1 || w.dim() == 2) && w.size(-1) == n_tasks,
+                      "merge_masked: weights are [n_tasks] or [n_sets, n_tasks]");
+    const int64_t n_sets = w.dim() == 2 ? w.size(0) : 1;
+    svdq_maskset *ms = nullptr;
+    check(svdq_maskset_create(&ms, (int32_t)P, rows.data()), "svdq_maskset_create");
+    struct Guard {
+        svdq_maskset *m;
+        c10::Device d;
+        ~Guard() {
+            sync(d);
+            svdq_maskset_destroy(m);
+        }
+    } ms_guard{ms, dev};
+    PlanKey key{rows, n_tasks, max_rank, bits, stages, energy, center, fp16, (int)dev.index(), stream};
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    std::unique_ptr<Plan> plan = acquire_plan(key, dev);
+    TORCH_CHECK_VALUE(small.numel() == plan->sizes.small_bytes && basis.numel() >= plan->sizes.basis_bytes,
+                      "merge_masked: small / basis are not the buffers of a plan with these masks and settings");
+    MaskWalk mw = mask_walk(ms, *plan, masks, rows, dev, stream, "merge_masked");
+    std::vector<at::Tensor> outs, bs;
+    for (int64_t p = 0; p < P; ++p) outs.push_back(floats_on(dev, rows[p]));
+    for (size_t p = 0; p < base.size(); ++p) {
+        TORCH_CHECK_VALUE(base[p].numel() == rows[p] && base[p].device() == dev, "merge_masked: base tensor ", p,
+                          " does not match");
+        bs.push_back(prep(base[p]));
+    }
+    at::Tensor otab = table_of(outs, dev), btab = bs.empty() ? at::Tensor() : table_of(bs, dev);
+    at::Tensor share;
+    if (n_sets > 1) share = at::full({n_sets}, 1.0 / (double)n_sets, at::TensorOptions().dtype(at::kFloat).device(dev));
+    at::Tensor fill = at::ones({P}, at::TensorOptions().dtype(at::kInt).device(dev));      // no noise regions here
+    at::Tensor work = bytes_on(dev, svdq_merge_work_bytes(plan->h, (int32_t)n_sets));
+    const int rc = svdq_merge_masked(plan->h, mw.ct.data_ptr<int64_t>(), small.data_ptr(), basis.data_ptr(),
+                                     (center && mean.numel() > 0) ? mean.data_ptr<float>() : nullptr, w.data_ptr<float>(),
+                                     nullptr, (int32_t)n_sets, 0, n_sets > 1 ? share.data_ptr<float>() : nullptr, nullptr,
+                                     mw.mtab.data_ptr(), mw.us.data_ptr<int64_t>(), fill.data_ptr<int32_t>(),
+                                     bs.empty() ? nullptr : btab.data_ptr(), otab.data_ptr(), work.data_ptr(), stream);
+    release_plan(std::move(key), std::move(plan));
+    check(rc, "svdq_merge_masked");
+    return outs;
+}
+
+// svdq_diagnostics / svdq_diagnostics_masked: [P, n_tasks, 6] float64 -- absolute_error, relative_error,
+// max_absolute_error, mean_absolute_error, original_norm, reconstructed_norm of every (parameter, task) against the
+// deltas the buffers were compressed from (masks empty: unmasked parameters)
+at::Tensor diagnostics(at::TensorList deltas, at::TensorList masks, const at::Tensor &small, const at::Tensor &basis,
+                       const at::Tensor &mean, int64_t n_tasks, double energy, int64_t max_rank, bool center, bool fp16,
+                       int64_t bits, int64_t stages, bool add_mean) {
+    std::vector<at::Tensor> vecs = prep_list(deltas, n_tasks, "diagnostics");
+    const c10::Device dev = vecs[0].device();
+    c10::DeviceGuard guard(dev);
+    void *stream = stream_of(dev);
+    std::vector<int64_t> rows = rows_of(vecs, n_tasks);
+    const int64_t P = (int64_t)rows.size();
+    TORCH_CHECK_VALUE(small.device() == dev && basis.device() == dev, "diagnostics: all tensors must live on one device");
+    svdq_maskset *ms = nullptr;
+    if (!masks.empty()) check(svdq_maskset_create(&ms, (int32_t)P, rows.data()), "svdq_maskset_create");
+    struct Guard {
+        svdq_maskset *m;
+        c10::Device d;
+        ~Guard() {
+            if (m) {
+                sync(d);
+                svdq_maskset_destroy(m);
+            }
+        }
+    } ms_guard{ms, dev};
+    PlanKey key{rows, n_tasks, max_rank, bits, stages, energy, center, fp16, (int)dev.index(), stream};
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    std::unique_ptr<Plan> plan = acquire_plan(key, dev);
+    TORCH_CHECK_VALUE(small.numel() == plan->sizes.small_bytes && basis.numel() >= plan->sizes.basis_bytes,
+                      "diagnostics: small / basis are not the buffers of a plan with these tensors and settings");
+    at::Tensor table = table_of(vecs, dev);
+    at::Tensor out = at::empty({P, n_tasks, 6}, at::TensorOptions().dtype(at::kDouble).device(dev));
+    at::Tensor work = bytes_on(dev, svdq_diagnostics_work_bytes(plan->h));
+    const float *mn = (center && mean.numel() > 0) ? mean.data_ptr<float>() : nullptr;
+    int rc;
+    if (ms) {
+        MaskWalk mw = mask_walk(ms, *plan, masks, rows, dev, stream, "diagnostics");
+        rc = svdq_diagnostics_masked(plan->h, table.data_ptr(), mw.mtab.data_ptr(), mw.us.data_ptr<int64_t>(),
+                                     mw.ct.data_ptr<int64_t>(), small.data_ptr(), basis.data_ptr(), mn, add_mean ? 1 : 0,
+                                     out.data_ptr<double>(), work.data_ptr(), stream);
+        sync(dev);      // the mask tables die with this scope
+    } else {
+        svdq_small_layout L{};
+        svdq_plan_small_layout(plan->h, &L);
+        rc = svdq_diagnostics(plan->h, table.data_ptr(),
+                              reinterpret_cast<const int64_t *>(small.data_ptr<uint8_t>() + L.rows_off), small.data_ptr(),
+                              basis.data_ptr(), mn, add_mean ? 1 : 0, out.data_ptr<double>(), work.data_ptr(), stream);
+        sync(dev);      // the pointer table dies with this scope
+    }
+    release_plan(std::move(key), std::move(plan));
+    check(rc, "svdq_diagnostics");
+    return out;
+}
+
 int64_t plan_cache_size() {
     std::lock_guard<std::mutex> lock(g_cache_mu);
     return (int64_t)g_cache.size();
@@ -650,6 +792,10 @@ TORCH_LIBRARY(svdq, m) {
     m.def("recon_error(Tensor U_high, Tensor U_low, Tensor coef, Tensor? mean, Tensor orig) -> Tensor");
     m.def("merge(Tensor small, Tensor basis, Tensor mean, int[] rows, int n_tasks, float energy, int max_rank, bool center, "
           "bool fp16, int bits, int stages, Tensor weights, Tensor[] base) -> Tensor[]");
+    m.def("merge_masked(Tensor small, Tensor basis, Tensor mean, Tensor[] masks, int n_tasks, float energy, int max_rank, "
+          "bool center, bool fp16, int bits, int stages, Tensor weights, Tensor[] base) -> Tensor[]");
+    m.def("diagnostics(Tensor[] deltas, Tensor[] masks, Tensor small, Tensor basis, Tensor mean, int n_tasks, float energy, "
+          "int max_rank, bool center, bool fp16, int bits, int stages, bool add_mean) -> Tensor");
     m.def("ingest(Tensor base, Tensor[] finetuned) -> Tensor[]");
     m.def("task_gram(Tensor[] deltas, int n_tasks) -> Tensor");
     m.def("plan_cache_size() -> int", plan_cache_size);
@@ -669,6 +815,8 @@ TORCH_LIBRARY_IMPL(svdq, CUDA, m) {
     m.impl("reconstruct", reconstruct);
     m.impl("recon_error", recon_error);
     m.impl("merge", merge);
+    m.impl("merge_masked", merge_masked);
+    m.impl("diagnostics", diagnostics);
     m.impl("ingest", ingest);
     m.impl("task_gram", task_gram);
 }

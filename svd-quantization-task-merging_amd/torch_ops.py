@@ -20,6 +20,10 @@ ATen arithmetic and no CPU implementation behind them.
     svdq::recon_error(Tensor U_high, Tensor U_low, Tensor coef, Tensor? mean, Tensor orig) -> Tensor
     svdq::merge(Tensor small, Tensor basis, Tensor mean, int[] rows, int n_tasks, <settings>, Tensor weights,
                 Tensor[] base) -> Tensor[]
+    svdq::merge_masked(Tensor small, Tensor basis, Tensor mean, Tensor[] masks, int n_tasks, <settings>,
+                       Tensor weights, Tensor[] base) -> Tensor[]      full-size tensors, the mask scatter fused
+    svdq::diagnostics(Tensor[] deltas, Tensor[] masks, Tensor small, Tensor basis, Tensor mean, int n_tasks,
+                      <settings>, bool add_mean) -> Tensor            float64 [P, n_tasks, 6]; masks [] = unmasked
     svdq::ingest(Tensor base, Tensor[] finetuned) -> Tensor[]
     svdq::task_gram(Tensor[] deltas, int n_tasks) -> Tensor
     svdq::plan_cache_size() -> int

@@ -7,7 +7,7 @@ import svdq_amd  # noqa: F401  (registers the operators when the libraries are a
 
 OPS = ("rtvq_quantize", "rtvq_dequantize", "mask_combine", "mask_select", "compress", "ingest", "task_gram",
        "compress_masked", "compress_gather", "compress_from_base", "mask_combine_indices", "reconstruct", "recon_error",
-       "merge")
+       "merge", "merge_masked", "diagnostics")
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -103,8 +103,9 @@ def test_ops_match_the_python_layer():
 
 @pytest.mark.gpu
 def test_masked_from_base_and_consumer_ops_match_the_ctypes_route():
-    """compress_masked / compress_gather / compress_from_base / mask_combine_indices / reconstruct / recon_error / merge:
-    every operator against the same entry point reached through ctypes (svdq_amd.pipeline), bit for bit."""
+    """compress_masked / compress_gather / compress_from_base / mask_combine_indices / reconstruct / recon_error / merge /
+    merge_masked / diagnostics: every operator against the same entry point reached through ctypes (svdq_amd.pipeline),
+    bit for bit."""
     from oracle import svd_hybrid_oracle as orc
     from svdq_amd.pipeline import CompressPlan
     from svdq_amd.mask_loader import MaskSet
@@ -174,6 +175,26 @@ def test_masked_from_base_and_consumer_ops_match_the_ctypes_route():
     torch.cuda.synchronize()
     for p, D in enumerate(sizes):
         assert torch.equal(outs[p], buf[offs[p]:offs[p] + D])
+    # plan-level diagnostics of the same buffers (the deltas of the from-base run are fine-tuned minus base)
+    d6 = torch.ops.svdq.diagnostics([f - base[p] for p, fs in enumerate(ft) for f in fs], [], small, basis, mean, N,
+                                    0.9, 0, True, True, 4, 2, False)
+    keepd = [[f - base[p] for f in fs] for p, fs in enumerate(ft)]
+    want6 = fb.diagnostics(fb.pointer_table(keepd))
+    torch.cuda.synchronize()
+    assert torch.equal(d6, want6)
+    # masked: the buffers of compress_masked, merged back to full size / diagnosed through the mask
+    small_m, basis_m, mean_m, rows_m = torch.ops.svdq.compress_masked(flat, masks, N, 0.9, 0, True, True, 4, 2)
+    outs_m = torch.ops.svdq.merge_masked(small_m, basis_m, mean_m, masks, N, 0.9, 0, True, True, 4, 2, w, base)
+    cbuf, coffs = ref.merge(w.view(1, N), rows_dev=ct)
+    torch.cuda.synchronize()
+    from svdq_amd.mask_loader import reconstruct_from_masked
+    for p, D in enumerate(sizes):
+        full = reconstruct_from_masked(cbuf[coffs[p]:coffs[p] + int(ct[p])], None, masks[p], masks[p].shape)
+        assert torch.equal(outs_m[p], base[p] + full)
+    dm = torch.ops.svdq.diagnostics(flat, masks, small_m, basis_m, mean_m, N, 0.9, 0, True, True, 4, 2, False)
+    wantm = ref.diagnostics_masked(ref.pointer_table(vecs), mtab, ms.unit_starts(ref, ct), ct)
+    torch.cuda.synchronize()
+    assert torch.equal(dm, wantm)
     # a mask on another device than the first is refused before any kernel runs (one GPU here: the CPU stands in)
     with pytest.raises((ValueError, RuntimeError, NotImplementedError)):
         torch.ops.svdq.mask_combine([masks[0], masks[0].cpu()], "union")
