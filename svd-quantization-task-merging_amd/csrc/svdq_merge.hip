@@ -250,16 +250,25 @@ struct ChunkSel {
     int rank[4];
     int count;
 };
-__device__ __forceinline__ ChunkSel chunk_select(mg_gbyte *__restrict__ gmask, int64_t src, int64_t hi, int inv,
-                                                 int64_t room, int lane) {
+// the chunk's mask bytes (0x100 = past the end of the range: selected by neither polarity), loaded one chunk ahead
+__device__ __forceinline__ void chunk_mask_load(unsigned (&mk)[4], mg_gbyte *__restrict__ gmask, int64_t src, int64_t hi,
+                                                int lane) {
+    const int64_t r = src + lane;
+    if (src + SVDQ_BLK_ROWS <= hi) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mk[e] = (unsigned)gmask[r + 64 * e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mk[e] = (r + 64 * e < hi) ? (unsigned)gmask[r + 64 * e] : 0x100u;
+    }
+}
+__device__ __forceinline__ ChunkSel chunk_select(const unsigned (&mk)[4], int inv, int64_t room) {
     ChunkSel c;
     int base = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int64_t r = src + 64 * e + lane;
-        c.in[e] = r < hi;
-        const unsigned mk = c.in[e] ? (unsigned)gmask[r] : 0x100u;
-        const bool s = inv ? (mk == 0u) : (mk != 0u && mk != 0x100u);
+        c.in[e] = mk[e] != 0x100u;
+        const bool s = inv ? (mk[e] == 0u) : (mk[e] != 0u && mk[e] != 0x100u);
         const unsigned long long bal = __ballot(s);
         c.rank[e] = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
         c.sel[e] = s && c.rank[e] < room;      // never past the unit's compacted rows, whatever the mask says
@@ -321,8 +330,19 @@ __global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict
     uint8_t *ldsUh = lds_raw;
     uint8_t *ldsUl = lds_raw + svdq_align_up((int64_t)SVDQ_BLK_ROWS * k * ES + 16, 16);
 
+    // the mask bytes and the base rows of a chunk do not depend on the selection: they are loaded one chunk ahead
+    unsigned mk[4];
+    float bnext[4];
+    auto ahead = [&](int64_t s0) {
+        chunk_mask_load(mk, gmask, s0, sr.hi, lane);
+        if (gbase) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) bnext[m] = (s0 + 64 * m + lane < sr.hi) ? gbase[s0 + 64 * m + lane] : 0.f;
+        }
+    };
+    ahead(sr.lo);
     for (int64_t src = sr.lo; src < sr.hi; src += SVDQ_BLK_ROWS) {
-        const ChunkSel cs = chunk_select(gmask, src, sr.hi, sr.inv, cend - cpos, lane);
+        const ChunkSel cs = chunk_select(mk, sr.inv, cend - cpos);
         int offh = 0, offl = 0;
         if (cs.count > 0) {
             if (k > 0) offh = stage_rows<ES>(ldsUh, gUh, cpos, cs.count, k, lane);
@@ -332,8 +352,9 @@ __global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             mv[m] = (gmean && cs.sel[m]) ? gmean[cpos + cs.rank[m]] : 0.f;
-            bv[m] = (gbase && cs.in[m]) ? gbase[src + 64 * m + lane] : 0.f;
+            bv[m] = gbase ? bnext[m] : 0.f;
         }
+        if (src + SVDQ_BLK_ROWS < sr.hi) ahead(src + SVDQ_BLK_ROWS);
         lds_fence();
         float res[4] = {0.f, 0.f, 0.f, 0.f};
         if (cs.count > 0) {
