@@ -160,6 +160,61 @@ def test_full_model_masked_union_gather():
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
+def test_full_model_masked_consumers_in_the_streaming_launches():
+    """The consumers of BASELINE configs[2] at full size (ViT-B-16 x 8, union mask, mask-walk compression): the merge with
+    the mask scatter inside the streaming launch (svdq_merge_masked, + base) against merging in the compacted row
+    space and expanding with torch's own boolean assignment -- bit for bit on every tensor; and the masked plan-level
+    diagnostics against the per-call fused error on torch's own `x[mask]` for two tensors."""
+    import svdq_amd
+    from svdq_amd import workloads
+    from svdq_amd.mask_loader import MaskSet
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    N = 8
+    shapes = workloads.vit_visual_shapes("ViT-B-16")
+    names = sorted(shapes)
+    rows = [workloads.numel(shapes[n]) for n in names]
+    bufs, views = workloads.synth_task_buffers(rows, N, seed=12, device=dev)
+    gm = torch.Generator(device=dev).manual_seed(6)
+    per_task = [[torch.rand(r, device=dev, generator=gm) > 0.7 for _ in range(N)] for r in rows]
+    ms = MaskSet(rows, dev)
+    kw = dict(energy_threshold=0.95, max_rank=64, center=True, fp16=True, low_bits=4, rtvq_stages=4, device=dev)
+    plan = CompressPlan(rows, N, **kw)
+    comb, ct, us = ms.prepare_combine_starts(per_task, "union", plan)
+    ms.run_combine_starts()
+    mtab = torch.tensor([c.data_ptr() for c in comb], dtype=torch.int64).to(dev)
+    table = plan.pointer_table(views)
+    plan.run_masked(table, mtab, us, ct)
+    sm = plan.fetch_small()
+    w = torch.tensor([[0.2, 0.05, 0.1, 0.15, 0.05, 0.25, 0.1, 0.1]], device=dev)
+    base = [torch.randn(r, device=dev, generator=gm) for r in rows]
+    btab = torch.tensor([b.data_ptr() for b in base], dtype=torch.int64).to(dev)
+    full = [torch.empty(r, device=dev) for r in rows]
+    otab = torch.tensor([f.data_ptr() for f in full], dtype=torch.int64).to(dev)
+    plan.merge_masked(w, mtab, us, ct, otab, fill=torch.ones(len(rows), dtype=torch.int32, device=dev), base_table=btab)
+    cbuf, coffs = plan.merge(w, rows_dev=ct)                       # the compacted rows, no base
+    torch.cuda.synchronize()
+    for p, r in enumerate(rows):
+        mask = comb[p].view(torch.bool)
+        want = torch.zeros(r, device=dev)
+        want[mask] = cbuf[coffs[p]:coffs[p] + int(sm.rows[p])]
+        assert torch.equal(full[p], base[p] + want), names[p]
+    res = plan.diagnostics_masked(table, mtab, us, ct).cpu().numpy()
+    for want_name in ("transformer.resblocks.7.mlp.c_fc.weight", "ln_pre.weight"):
+        p = names.index(want_name)
+        mask = comb[p].view(torch.bool)
+        k, r_ = int(sm.k[p]), int(sm.r[p])
+        Uh, Ul, _ = plan.basis_tensors(p, k, r_, int(sm.rows[p]))
+        quant = svdq_amd.RTVQQuantizer(4, 4)
+        for t in (0, 5):
+            art = svdq_amd.pipeline.task_artifact(plan, sm, p, t)
+            cl = quant.dequantize(art["c_low_quant"], device=dev).float()
+            ref6 = svdq_amd.diagnostics._fused_error(views[p][t][mask].contiguous(), Uh, Ul,
+                                                     art["c_high_fp16"].to(dev).float(), cl, dev)
+            for j, key in enumerate(svdq_amd.diagnostics._KEYS):
+                assert res[p, t, j] == pytest.approx(ref6[key], rel=1e-6, abs=1e-12), (want_name, t, key)
+
+
 def test_config5_vitl14_x20_mixed_widths_cluster_merge():
     """BASELINE configs[4] at full size on one GPU: ViT-L-14 x 20 tasks, mixed code widths inside ONE run (8-bit for
     the matrices, 2-bit for the vectors: config.svd_low_bits_by_param), cluster_tasks(k=2) -> compute_weights("cluster")
