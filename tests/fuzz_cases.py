@@ -2,8 +2,10 @@
 
 oracle_case : random (D, N, thresholds, centre, fp16, bits, stages) against the CPU oracle (the restated reference op
               sequence): singular values, rank, retained energy, reconstructions.
-modes_case  : gather mode (against compacted copies), minus-base mode (against ingest + compress) and both combined
-              (against ingest + gather) must reproduce the plain path bit for bit.
+modes_case  : gather mode (against compacted copies), minus-base mode (against ingest + compress), both combined
+              (against ingest + gather) and the mask walk must reproduce the plain path bit for bit; the masked
+              consumers (svdq_merge_masked, svdq_diagnostics_masked) must reproduce merge / diagnostics of the
+              compacted copies.
 Each returns a (description, [mismatch messages]) pair; an empty list means the case is within tolerance."""
 import random
 
@@ -186,6 +188,33 @@ def modes_case(sq, dev, seed: int, c: int):
     m = _same(r4, gb)
     if m:
         msgs.append("gather_from_base: " + m)
+    # the consumers of a masked plan: merge with the mask scatter inside the streaming launch (svdq_merge_masked, + base)
+    # against merging the compacted rows and scattering with torch's boolean assignment -- bit for bit; the masked
+    # plan-level diagnostics against the plain ones on the compacted copies (fp64 sums in another order)
+    mtab_i = torch.tensor([x.data_ptr() for x in ms._i["mb"]], dtype=torch.int64).to(dev)
+    us_g = ms.unit_starts(ga, ct2, mask_table=mtab_i)
+    wts = torch.rand(1, N, device=dev, generator=g) + 0.1
+    wts = (wts / wts.sum()).contiguous()
+    full = [torch.empty(D, device=dev) for D in sizes]
+    otab = torch.tensor([f.data_ptr() for f in full], dtype=torch.int64).to(dev)
+    btab_c = torch.tensor([b.data_ptr() for b in base], dtype=torch.int64).to(dev)
+    ga.merge_masked(wts, mtab_i, us_g, ct2, otab, fill=torch.ones(P, dtype=torch.int32, device=dev), base_table=btab_c)
+    cbuf, coffs = r3.merge(wts, rows_dev=ct)
+    torch.cuda.synchronize()
+    counts = ct.cpu().tolist()
+    for p in range(P):
+        want = torch.zeros(sizes[p], device=dev)
+        want[masks[p]] = cbuf[coffs[p]:coffs[p] + counts[p]]
+        want = base[p] + want
+        if not torch.equal(torch.nan_to_num(full[p], nan=7.0), torch.nan_to_num(want, nan=7.0)):
+            msgs.append(f"merge_masked: parameter {p} differs")
+            break
+    dm = ga.diagnostics_masked(ga.pointer_table(deltas), mtab_i, us_g, ct2).cpu().numpy()
+    dc = r3.diagnostics(r3.pointer_table(dt), ct).cpu().numpy()
+    ok = np.isclose(dm, dc, rtol=1e-6, atol=1e-12) | (np.isnan(dm) & np.isnan(dc))
+    if not ok.all():
+        p_, t_, j_ = [int(v[0]) for v in np.nonzero(~ok)]
+        msgs.append(f"diagnostics_masked: parameter {p_} task {t_} field {j_}: {dm[p_, t_, j_]} vs {dc[p_, t_, j_]}")
     extra = []
     if N <= 16:
         # the mask walk (no index lists): against the compacted run, and straight from checkpoints against ingest + walk
