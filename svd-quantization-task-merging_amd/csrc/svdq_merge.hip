@@ -437,7 +437,6 @@ struct DiagPart {
 // WALK: the block is a chunk of 256 SOURCE rows of a masked region (k_merge_expand's walk); selected rows are written
 // to X at their rank, so the compute phase is the same loop over `count` compacted rows.  The next chunk's basis run
 // starts where this one ends; its length is not known before its mask is, so 256 rows (clamped to the unit) are fetched.
-#define DG_TPW 8
 #define DG_XS (SVDQ_BLK_ROWS + 64)      // X row: 256 rows + one dump slot per lane (unselected rows are written there: no branch)
 
 struct UStage {      // where a block's staged basis rows sit (wave-uniform)
@@ -459,8 +458,8 @@ __device__ __forceinline__ UStage ustage_plan(int64_t c0, int nr, int k, int nl)
     return u;
 }
 
-template <int W, bool U16, bool WALK>
-__global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict__ params,
+template <int W, int TPW, bool U16, bool WALK>
+__global__ __launch_bounds__(64 * W, (TPW == 4 ? 4 : 2)) void k_diag(const SvdqParam *__restrict__ params,
                                                   const SvdqUnit *__restrict__ units,
                                                   const float *const *__restrict__ ptrs,
                                                   const uint8_t *const *__restrict__ mask_ptrs,
@@ -473,16 +472,16 @@ __global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict_
     using T = typename UElem<U16>::type;
     constexpr int ES = U16 ? 2 : 4;
     // 16-byte vectors of one block's basis rows per thread: 256 rows x 8 W columns x ES bytes over 64 W threads, + ends
-    constexpr int SV = (SVDQ_BLK_ROWS * DG_TPW * ES / 16) / 64 + 1;
+    constexpr int SV = (SVDQ_BLK_ROWS * TPW * ES / 16) / 64 + 1;      // 16 n ES + 4 vectors over 64 W threads, n <= TPW W
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = NT, u = blockIdx.x;
     const int ubytes = (int)svdq_align_up((int64_t)SVDQ_BLK_ROWS * n * ES + 64, 16);
     uint8_t *Ubuf = lds_raw;                                                  // two buffers
-    float *Cw = reinterpret_cast<float *>(lds_raw + 2 * ubytes) + (size_t)w * n * DG_TPW;   // [column][8 tasks] per wave
-    float *Xw = reinterpret_cast<float *>(lds_raw + 2 * ubytes) + (size_t)W * n * DG_TPW +
-                (size_t)w * (DG_TPW + 1) * DG_XS;                             // [8 tasks + mean][256 rows + dump] per wave
-    const int t0 = w * DG_TPW;
-    const int nt = (n - t0 < DG_TPW) ? (n - t0) : DG_TPW;      // tasks of this wave (>= 1: W = ceil(N / 8))
+    float *Cw = reinterpret_cast<float *>(lds_raw + 2 * ubytes) + (size_t)w * n * TPW;   // [column][8 tasks] per wave
+    float *Xw = reinterpret_cast<float *>(lds_raw + 2 * ubytes) + (size_t)W * n * TPW +
+                (size_t)w * (TPW + 1) * DG_XS;                             // [8 tasks + mean][256 rows + dump] per wave
+    const int t0 = w * TPW;
+    const int nt = (n - t0 < TPW) ? (n - t0) : TPW;      // tasks of this wave (>= 1: W = ceil(N / 8))
     const SvdqUnit ud = units[u];
     const int p = ud.param;
     const SvdqParam pd = params[p];
@@ -490,17 +489,17 @@ __global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict_
     int64_t cpos = ud.row0;
     int64_t cend = ud.row0 + ud.nrows;
     if (cend > D) cend = D;
-    double se[DG_TPW], sx[DG_TPW], sr[DG_TPW], sa[DG_TPW];
-    float mx[DG_TPW];
+    double se[TPW], sx[TPW], sr[TPW], sa[TPW];
+    float mx[TPW];
 #pragma unroll
-    for (int a = 0; a < DG_TPW; ++a) {
+    for (int a = 0; a < TPW; ++a) {
         se[a] = sx[a] = sr[a] = sa[a] = 0.0;
         mx[a] = 0.f;
     }
     if (cpos < cend) {      // workgroup-uniform
         const int k = k_in[p], r = r_in[p], nl = r - k;
-        for (int e = lane; e < n * DG_TPW; e += 64) {      // this wave's coefficient table, [column][task]
-            const int c = e / DG_TPW, a = e % DG_TPW;
+        for (int e = lane; e < n * TPW; e += 64) {      // this wave's coefficient table, [column][task]
+            const int c = e / TPW, a = e % TPW;
             Cw[e] = (a < nt) ? ctask[(size_t)p * n * n + (size_t)(t0 + a) * n + c] : 0.f;
         }
         const uint8_t *slab = basis + pd.slab_off;
@@ -508,9 +507,9 @@ __global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict_
         const uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
         mg_gfloat *gmean = (add_mean && meanbuf) ? (mg_gfloat *)(meanbuf + pd.mean_off) : nullptr;
         mg_gbyte *gmask = WALK ? (mg_gbyte *)mask_ptrs[p] : nullptr;
-        mg_gfloat *dp[DG_TPW];
+        mg_gfloat *dp[TPW];
 #pragma unroll
-        for (int a = 0; a < DG_TPW; ++a) dp[a] = (mg_gfloat *)ptrs[(size_t)p * n + t0 + (a < nt ? a : 0)];
+        for (int a = 0; a < TPW; ++a) dp[a] = (mg_gfloat *)ptrs[(size_t)p * n + t0 + (a < nt ? a : 0)];
         int64_t src = cpos, src_hi = cend;      // plain: source rows = compacted rows
         int inv = 0;
         if constexpr (WALK) {
@@ -520,7 +519,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict_
             inv = rg.inv;
         }
         // ---- the loads of one block into registers
-        float xpf[DG_TPW][4] = {}, mpf[4];
+        float xpf[TPW][4] = {}, mpf[4];
         unsigned mkpf[4];
         f32x4 ureg[SV];
         UStage us;
@@ -531,7 +530,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict_
                 for (int e = 0; e < 4; ++e)
                     if constexpr (WALK) mkpf[e] = (unsigned)gmask[r0 + 64 * e];
 #pragma unroll
-                for (int a = 0; a < DG_TPW; ++a)
+                for (int a = 0; a < TPW; ++a)
                     if (a < nt) {      // wave-uniform
 #pragma unroll
                         for (int e = 0; e < 4; ++e) xpf[a][e] = dp[a][r0 + 64 * e];
@@ -544,7 +543,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict_
                     if constexpr (WALK) mkpf[e] = in[e] ? (unsigned)gmask[r0 + 64 * e] : 0x100u;
                 }
 #pragma unroll
-                for (int a = 0; a < DG_TPW; ++a)
+                for (int a = 0; a < TPW; ++a)
                     if (a < nt) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) xpf[a][e] = in[e] ? dp[a][r0 + 64 * e] : 0.f;
@@ -602,14 +601,14 @@ __global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict_
             }
             if (gmean) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Xw[DG_TPW * DG_XS + 64 * e + lane] = mpf[e];
+                for (int e = 0; e < 4; ++e) Xw[TPW * DG_XS + 64 * e + lane] = mpf[e];
             }
             {
                 int slot[4];      // a selected row goes to its rank, any other to the lane's dump slot
 #pragma unroll
                 for (int e = 0; e < 4; ++e) slot[e] = sel[e] ? rank[e] : SVDQ_BLK_ROWS + lane;
 #pragma unroll
-                for (int a = 0; a < DG_TPW; ++a)      // all eight strips (those past the wave's tasks hold don't-cares)
+                for (int a = 0; a < TPW; ++a)      // all eight strips (those past the wave's tasks hold don't-cares)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) Xw[a * DG_XS + slot[e]] = xpf[a][e];
             }
@@ -630,39 +629,39 @@ __global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict_
                 const int qa = 128 * h + lane, qb = qa + 64;
                 const bool va = qa < count, vb = qb < count;
                 const int ra = va ? qa : 0, rb = vb ? qb : 0;
-                float hi[2][DG_TPW], lo[2][DG_TPW];
+                float hi[2][TPW], lo[2][TPW];
 #pragma unroll
-                for (int a = 0; a < DG_TPW; ++a) hi[0][a] = hi[1][a] = lo[0][a] = lo[1][a] = 0.f;
+                for (int a = 0; a < TPW; ++a) hi[0][a] = hi[1][a] = lo[0][a] = lo[1][a] = 0.f;
 #pragma unroll 4
                 for (int c = 0; c < k; ++c) {
-                    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cw + c * DG_TPW);
-                    const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cw + c * DG_TPW + 4);
                     const float ua = u_val(Uh, ra * k + c), ub = u_val(Uh, rb * k + c);
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        hi[0][a] = fmaf(ua, c0[a], hi[0][a]);
-                        hi[0][a + 4] = fmaf(ua, c1[a], hi[0][a + 4]);
-                        hi[1][a] = fmaf(ub, c0[a], hi[1][a]);
-                        hi[1][a + 4] = fmaf(ub, c1[a], hi[1][a + 4]);
+                    for (int g = 0; g < TPW; g += 4) {
+                        const f32x4 cq = *reinterpret_cast<const f32x4 *>(Cw + c * TPW + g);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            hi[0][g + a] = fmaf(ua, cq[a], hi[0][g + a]);
+                            hi[1][g + a] = fmaf(ub, cq[a], hi[1][g + a]);
+                        }
                     }
                 }
 #pragma unroll 4
                 for (int jx = 0; jx < nl; ++jx) {
-                    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cw + (k + jx) * DG_TPW);
-                    const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cw + (k + jx) * DG_TPW + 4);
                     const float ua = u_val(Ul, ra * nl + jx), ub = u_val(Ul, rb * nl + jx);
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        lo[0][a] = fmaf(ua, c0[a], lo[0][a]);
-                        lo[0][a + 4] = fmaf(ua, c1[a], lo[0][a + 4]);
-                        lo[1][a] = fmaf(ub, c0[a], lo[1][a]);
-                        lo[1][a + 4] = fmaf(ub, c1[a], lo[1][a + 4]);
+                    for (int g = 0; g < TPW; g += 4) {
+                        const f32x4 cq = *reinterpret_cast<const f32x4 *>(Cw + (k + jx) * TPW + g);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            lo[0][g + a] = fmaf(ua, cq[a], lo[0][g + a]);
+                            lo[1][g + a] = fmaf(ub, cq[a], lo[1][g + a]);
+                        }
                     }
                 }
-                const float ma = gmean ? Xw[DG_TPW * DG_XS + ra] : 0.f;
-                const float mb = gmean ? Xw[DG_TPW * DG_XS + rb] : 0.f;
+                const float ma = gmean ? Xw[TPW * DG_XS + ra] : 0.f;
+                const float mb = gmean ? Xw[TPW * DG_XS + rb] : 0.f;
 #pragma unroll
-                for (int a = 0; a < DG_TPW; ++a) {      // no branch on the wave's task count: strips past it are never stored
+                for (int a = 0; a < TPW; ++a) {      // no branch on the wave's task count: strips past it are never stored
                     {
                         // the lane's two rows: products and their two-term sums in fp32 (each term is a rounded fp32
                         // square -- what the reference's fp32 norms see), the running sums in fp64.  Rows past the
@@ -693,7 +692,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_diag(const SvdqParam *__restrict_
     }
     // wave reduction in a fixed order (xor butterflies), lane 0 writes the unit's partials of the wave's tasks
 #pragma unroll
-    for (int a = 0; a < DG_TPW; ++a) {
+    for (int a = 0; a < TPW; ++a) {
         double qa = se[a], qb = sx[a], qc = sr[a], qd = sa[a];
         float q = mx[a];
 #pragma unroll
@@ -901,7 +900,7 @@ __global__ void k_one_hot(int n, float *w) {
     if (e < n * n) w[e] = (e / n == e % n) ? 1.f : -1.f;
 }
 
-template <int W>
+template <int W, int TPW>
 static void launch_diag(const svdq_plan *pl, const void *ptrs, const void *mask_ptrs, const int64_t *unit_start,
                         const int64_t *rows_dev, const int32_t *kk, const int32_t *rr, const uint8_t *basis,
                         const float *mean, int add_mean, const float *ctask, DiagPart *part, hipStream_t st) {
@@ -909,13 +908,13 @@ static void launch_diag(const svdq_plan *pl, const void *ptrs, const void *mask_
     auto mp = reinterpret_cast<const uint8_t *const *>(mask_ptrs);
     const int n = pl->n_tasks, es = pl->cfg.fp16 ? 2 : 4;
     const size_t lds = 2 * (size_t)svdq_align_up((int64_t)SVDQ_BLK_ROWS * n * es + 64, 16) +
-                       (size_t)W * n * DG_TPW * 4 + (size_t)W * (DG_TPW + 1) * DG_XS * 4;
+                       (size_t)W * n * TPW * 4 + (size_t)W * (TPW + 1) * DG_XS * 4;
 #define SVDQ_DIAG_LAUNCH(F16, WALK_)                                                                                   \
     do {                                                                                                               \
         if (lds > 65536)                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<W, F16, WALK_>),                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<W, TPW, F16, WALK_>),                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-        hipLaunchKernelGGL((k_diag<W, F16, WALK_>), dim3(pl->n_units), dim3(64 * W), lds, st, pl->d_params,             \
+        hipLaunchKernelGGL((k_diag<W, TPW, F16, WALK_>), dim3(pl->n_units), dim3(64 * W), lds, st, pl->d_params,        \
                            pl->d_units, pp, mp, unit_start, rows_dev, n, kk, rr, basis, mean, add_mean, ctask, part);  \
     } while (0)
     if (pl->cfg.fp16) {
@@ -947,9 +946,12 @@ static int run_diagnostics(const char *who, const svdq_plan *pl, const void *del
     const uint8_t *sm = reinterpret_cast<const uint8_t *>(small);
     auto kk = reinterpret_cast<const int32_t *>(sm + L.k_off), rr = reinterpret_cast<const int32_t *>(sm + L.r_off);
     auto bs = reinterpret_cast<const uint8_t *>(basis);
+    // eight tasks per wavefront.  (Four -- twice the wavefronts, 128 registers, four waves per SIMD -- measured 1.5x
+    // SLOWER: 5.21 against 3.43 ms at ViT-L-14 x 8; the kernel is bound by instruction issue, and the second wave's
+    // own copy of the row reads, conversions and barriers costs more than the extra resident waves hide.)
 #define SVDQ_DIAG_CASE(W_) \
-    case W_: launch_diag<W_>(pl, delta_ptrs, mask_ptrs, unit_start, rows_dev, kk, rr, bs, mean, add_mean, ctask, part, st); break
-    switch ((int)((n + DG_TPW - 1) / DG_TPW)) {
+    case W_: launch_diag<W_, 8>(pl, delta_ptrs, mask_ptrs, unit_start, rows_dev, kk, rr, bs, mean, add_mean, ctask, part, st); break
+    switch ((int)((n + 7) / 8)) {
         SVDQ_DIAG_CASE(1); SVDQ_DIAG_CASE(2); SVDQ_DIAG_CASE(3); SVDQ_DIAG_CASE(4);
         default:
             svdq_set_error("%s: unsupported task count %d", who, (int)n);
