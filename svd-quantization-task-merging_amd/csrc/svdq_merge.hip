@@ -12,11 +12,16 @@
 //                        weighting.py:332-372 -- the merge is linear, so any number of clusters costs one pass over U),
 //                        + base (apply_merged_deltas merge.py:429-552) when asked.  HBM-bound: reads the basis once
 //                        (e (k + nl) B/row), mean and base, writes 4 B/row.
+//   k_merge_expand       the same for MASKED regions with reconstruct_from_masked (mask_loader.py:712-763) inside: walks the
+//                        source rows with the combined mask byte beside them, writes every merged row at its source
+//                        position (signal and noise regions each their own rows of the full tensor).
 //   k_diag / k_diag_finish  compute_parameter_diagnostics' inner loop (diagnostics.py:186-215) for all N tasks of a
-//                        parameter in one pass over U and the N deltas: N error tuples per parameter.
+//                        parameter in one pass over U and the N deltas: N error tuples per parameter; walk mode =
+//                        masked regions, apply_mask_to_tensor (mask_loader.py:651-679) inside the pass.
 //
 // Per-row arithmetic is that of k_reconstruct / k_recon_error (svdq_elem.hip): fp32 fma chains from 0 over the columns
-// in order, hi + lo, + mean, * scale -- so a parameter's merged rows are the same bits as the per-parameter route's.
+// in order, hi + lo, + mean, * scale -- so a parameter's merged rows are the same bits as the per-parameter route's
+// (the diagnostics' sums run in another order: equal to the last digits of the fp64 accumulators).
 
 #include "svdq_common.h"
 #include <hip/hip_fp16.h>
