@@ -391,3 +391,35 @@ def test_batched_diagnostics_match_per_parameter(sq, with_masks):
             assert f[key] == pytest.approx(s[key], rel=1e-6, abs=1e-12)
     for key, v in slow["summary"].items():
         assert fast["summary"][key] == pytest.approx(v, rel=1e-6)
+
+
+@pytest.mark.parametrize("n_tasks,fp16", [(12, True), (20, False), (28, True), (32, False)])
+def test_plan_diagnostics_at_larger_task_counts(sq, n_tasks, fp16):
+    """svdq_diagnostics with two to four wavefronts per work unit (tasks split eight per wavefront; from 25 tasks on the
+    kernel needs more than 64 KB of LDS) against the per-call fused error, every (parameter, task)."""
+    from oracle import svd_hybrid_oracle as orc
+    from svdq_amd import diagnostics as dg
+    from svdq_amd.pipeline import CompressPlan, task_artifact
+    dev = torch.device("cuda", 0)
+    sizes = [9000, 257, 4096 * 3 + 5]
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, n_tasks, 300 + i, rank=3)] for i, D in enumerate(sizes)]
+    plan = CompressPlan(sizes, n_tasks, energy_threshold=0.9, max_rank=None, center=True, fp16=fp16, low_bits=4,
+                        rtvq_stages=2, device=dev)
+    table = plan.pointer_table(vecs)
+    plan.run(table)
+    sm = plan.fetch_small()
+    res = plan.diagnostics(table).cpu().numpy()
+    with_mean = plan.diagnostics(table, add_mean=True).cpu().numpy()
+    quant = sq.RTVQQuantizer(4, 2)
+    for p, D in enumerate(sizes):
+        k, r = int(sm.k[p]), int(sm.r[p])
+        Uh, Ul, mu = plan.basis_tensors(p, k, r, D)
+        for t in range(n_tasks):
+            art = task_artifact(plan, sm, p, t)
+            cl = quant.dequantize(art["c_low_quant"], device=dev).float()
+            ref6 = dg._fused_error(vecs[p][t], Uh, Ul, art["c_high_fp16"].to(dev).float(), cl, dev)
+            for j, key in enumerate(dg._KEYS):
+                assert res[p, t, j] == pytest.approx(ref6[key], rel=1e-6, abs=1e-12), (p, t, key)
+        # with the mean added back the reconstruction is close to the delta itself (Q1: the reference leaves it out)
+        assert (with_mean[p, :, 1] < res[p, :, 1] + 1e-9).all()
+    plan.close()
