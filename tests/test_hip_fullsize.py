@@ -345,12 +345,13 @@ def test_single_tensor_beyond_2_pow_30_rows():
         v.mul_(0.3).add_(shared, alpha=0.5 + 0.25 * t)
         vecs.append(v)
     del shared
-    plan = CompressPlan([D], N, energy_threshold=0.9, max_rank=None, center=True, fp16=True, low_bits=4, rtvq_stages=2,
+    # max_rank = 1: two coefficients are quantized per task (one alone would be the reference's degenerate min == max case)
+    plan = CompressPlan([D], N, energy_threshold=0.9, max_rank=1, center=True, fp16=True, low_bits=4, rtvq_stages=2,
                         device=dev)
     plan.run(plan.pointer_table([vecs]))
     sm = plan.fetch_small()
     k, r = int(sm.k[0]), int(sm.r[0])
-    assert int(sm.rows[0]) == D and r == N and 1 <= k <= r
+    assert int(sm.rows[0]) == D and r == N and k == 1
     # fp64 Gram of the centred columns, in chunks
     G = torch.zeros(N, N, dtype=torch.float64, device=dev)
     step = 1 << 26
@@ -382,6 +383,26 @@ def test_single_tensor_beyond_2_pow_30_rows():
         ms = Xs.mean(dim=1, keepdim=True)
         Us = torch.cat([U_high[sl], U_low[sl]], dim=1).float()
         assert float((Us @ coef.T + ms - Xs).abs().max()) < 2e-3 * scale
+    # the plan-level consumers at this size (64-bit offsets in k_merge_reconstruct / k_diag): the merge against torch on
+    # slices at both ends and across row 2^30, the diagnostics against the per-call fused error of one task
+    import svdq_amd
+    w = torch.tensor([[0.5, 0.3, 0.2]], device=dev)
+    buf, offs = plan.merge(w)
+    quant = svdq_amd.RTVQQuantizer(4, 2)
+    cs = []
+    for t in range(N):
+        art = svdq_amd.pipeline.task_artifact(plan, sm, 0, t)
+        cs.append(torch.cat([art["c_high_fp16"].to(dev).float(), quant.dequantize(art["c_low_quant"], device=dev).float()]))
+    cbar = sum(float(w[0, t]) * cs[t] for t in range(N))
+    for lo in (1, (1 << 30) - 2500, D - 5000):
+        sl = slice(lo, lo + 5000)
+        Us = torch.cat([U_high[sl], U_low[sl]], dim=1).float()
+        want = Us @ cbar + mean[sl].flatten()
+        assert torch.allclose(buf[offs[0] + lo:offs[0] + lo + 5000], want, rtol=1e-4, atol=1e-5 * scale)
+    res = plan.diagnostics(plan.pointer_table([vecs])).cpu().numpy()
+    ref6 = svdq_amd.diagnostics._fused_error(vecs[1], U_high, U_low, cs[1][:k], cs[1][k:], dev)
+    for j, key in enumerate(svdq_amd.diagnostics._KEYS):
+        assert res[0, 1, j] == pytest.approx(ref6[key], rel=1e-6, abs=1e-12), key
 
 
 def test_quantizer_beyond_2_pow_31_elements():
