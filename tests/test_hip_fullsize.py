@@ -465,3 +465,82 @@ def test_mask_apply_beyond_2_pow_31_elements():
             pos += want.numel()
         assert pos == got.numel()
         del got
+
+
+def test_mask_walk_beyond_2_pow_31_source_elements():
+    """Maximum sizes for the mask walk: one parameter of 2^31 + 777 SOURCE elements (past what int32 index lists can
+    address: svdq_maskset_indices refuses it), density 0.9, N = 3.  Compression through count + scan + unit starts +
+    svdq_compress_masked, then the masked merge with the scatter inside the launch.  Checked at the far end of the
+    tensor, where a 32-bit source position or compacted row would show: mean, rows rebuilt from the fp16 basis, and the
+    merged full-size tensor (values at selected positions, exact zeros elsewhere)."""
+    import svdq_amd
+    from svdq_amd.mask_loader import MaskSet
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    D, N = (1 << 31) + 777, 3
+    g = torch.Generator(device=dev).manual_seed(21)
+    step = 1 << 29
+    mask = torch.empty(D, dtype=torch.bool, device=dev)
+    shared = torch.empty(D, device=dev)
+    for a in range(0, D, step):
+        b = min(D, a + step)
+        mask[a:b] = torch.rand(b - a, generator=g, device=dev) < 0.9
+        torch.randn(b - a, generator=g, device=dev, out=shared[a:b])
+    vecs = []
+    for t in range(N):
+        v = torch.empty(D, device=dev)
+        for a in range(0, D, step):
+            b = min(D, a + step)
+            torch.randn(b - a, generator=g, device=dev, out=v[a:b])
+        v.mul_(0.3).add_(shared, alpha=0.5 + 0.25 * t)
+        vecs.append(v)
+    del shared
+    ms = MaskSet([D], dev)
+    with pytest.raises(Exception, match="2\\^31"):
+        ms.indices([mask], want_false=False)                      # the index-list route cannot address this tensor
+    ct, _ = ms.count_scan([mask])
+    count = int(ct[0])
+    assert count == sum(int(mask[a:a + step].sum()) for a in range(0, D, step)) and count > (1 << 30)
+    plan = CompressPlan([D], N, energy_threshold=0.9, max_rank=1, center=True, fp16=True, low_bits=4, rtvq_stages=2,
+                        device=dev)
+    mtab = torch.tensor([ms._s["mb"][0].data_ptr()], dtype=torch.int64).to(dev)
+    us = ms.unit_starts(plan, ct)
+    table = plan.pointer_table([vecs])
+    plan.run_masked(table, mtab, us, ct)
+    sm = plan.fetch_small()
+    k, r = int(sm.k[0]), int(sm.r[0])
+    assert int(sm.rows[0]) == count and r == N and k == 1
+    U_high, U_low, mean = plan.basis_tensors(0, k, r, count)
+    coef = torch.from_numpy(sm.coef[0, :N, :r].copy()).to(dev)
+    # windows of source rows at the far end and across source position 2^31; the compacted row of the window's first
+    # selected element = number of selected elements in front of it
+    for lo in (D - 6000, (1 << 31) - 3000):
+        front = sum(int(mask[a:min(lo, a + step)].sum()) for a in range(0, lo, step))
+        sel = mask[lo:lo + 6000]
+        nsel = int(sel.sum())
+        Xs = torch.stack([v[lo:lo + 6000][sel] for v in vecs], dim=1)
+        ms_ = Xs.mean(dim=1, keepdim=True)
+        assert torch.allclose(mean[front:front + nsel], ms_, rtol=1e-5, atol=1e-6)
+        Us = torch.cat([U_high[front:front + nsel], U_low[front:front + nsel]], dim=1).float()
+        scale = float(Xs.abs().max())
+        assert float((Us @ coef.T + ms_ - Xs).abs().max()) < 2e-3 * scale
+    # the masked merge, scatter inside the launch
+    w = torch.tensor([[0.5, 0.3, 0.2]], device=dev)
+    full = torch.empty(D, device=dev)
+    plan.merge_masked(w, mtab, us, ct, torch.tensor([full.data_ptr()], dtype=torch.int64).to(dev),
+                      fill=torch.ones(1, dtype=torch.int32, device=dev))
+    quant = svdq_amd.RTVQQuantizer(4, 2)
+    cs = []
+    for t in range(N):
+        art = svdq_amd.pipeline.task_artifact(plan, sm, 0, t)
+        cs.append(torch.cat([art["c_high_fp16"].to(dev).float(), quant.dequantize(art["c_low_quant"], device=dev).float()]))
+    cbar = sum(float(w[0, t]) * cs[t] for t in range(N))
+    for lo in (0, (1 << 31) - 3000, D - 6000):
+        front = sum(int(mask[a:min(lo, a + step)].sum()) for a in range(0, lo, step))
+        sel = mask[lo:lo + 6000]
+        nsel = int(sel.sum())
+        Us = torch.cat([U_high[front:front + nsel], U_low[front:front + nsel]], dim=1).float()
+        want = torch.zeros(sel.numel(), device=dev)
+        want[sel] = Us @ cbar + mean[front:front + nsel].flatten()
+        got = full[lo:lo + 6000]
+        assert torch.equal(got[~sel], want[~sel]) and torch.allclose(got[sel], want[sel], rtol=1e-4, atol=1e-5), lo
