@@ -100,13 +100,15 @@ def oracle_case(sq, orc, dev, seed: int, c: int):
         # With at most SIGN_ENUM quantized directions the sign freedom is enumerated instead of bounded: the basis is
         # orthonormal, so a sign choice s changes the error by sum_t |c_low s - dequantize(quantize(c_low s))|^2 only
         # (fuzz seed 304 case 144: three directions, 2 bits -> 2.65e-4 .. 4.67e-4 rms over the eight choices, and
-        # the device's basis lands on one of them).  The worst choice, with 10 % on top for the basis rounding, is the
+        # the device's basis lands on one of them; seed 5001 case 807: five directions with a near-degenerate pair,
+        # 5.0e-4 .. 1.78e-3 over the sign choices alone -- the reference's own basis being the best of them -- and up
+        # to 3.2e-3 with rotations inside the pair).  The worst choice, with 10 % on top for the basis rounding, is the
         # bound there.
         low = S_ref[k:r][real[k:r]]
         clustered = low.size >= 2 and bool(np.any(np.abs(np.diff(low)) < 0.05 * low[:-1]))
         bound = 2.5 if clustered else 1.5
         limit = bound ** 2 * er2
-        if coarse and not clustered and r - k <= SIGN_ENUM:
+        if coarse and r - k <= SIGN_ENUM:      # (a cluster only adds rotations on top of the sign choices)
             limit = max(limit, 1.1 ** 2 * _worst_sign_error(orc, ref, er2, bits, stages))
         if coarse and eo2 > limit + 1e-12:
             msgs.append(f"rms recon error vs original {eo2 ** 0.5:.3e} vs reference {er2 ** 0.5:.3e} "
