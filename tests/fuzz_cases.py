@@ -1,7 +1,10 @@
 """Randomised parity cases shared by the GPU test-suite (a seeded subset) and tools/fuzz_*.py (long runs).
 
 oracle_case : random (D, N, thresholds, centre, fp16, bits, stages) against the CPU oracle (the restated reference op
-              sequence): singular values, rank, retained energy, reconstructions.
+              sequence): singular values, rank, retained energy, reconstructions; and, free of the basis freedom,
+              the span of U_high (principal angles against the reference's, where a gap makes it unique), the
+              projections on the device's own basis (fp64 on the host) and the reference quantizer on the device's
+              own c_low, bit for bit.
 modes_case  : gather mode (against compacted copies), minus-base mode (against ingest + compress), both combined
               (against ingest + gather) and the mask walk must reproduce the plain path bit for bit; the masked
               consumers (svdq_merge_masked, svdq_diagnostics_masked) must reproduce merge / diagnostics of the
@@ -65,6 +68,57 @@ def oracle_case(sq, orc, dev, seed: int, c: int):
     near = np.any(np.abs(cum - thr) < 1e-4)
     if not near and k != ref["basis"]["k"]:
         msgs.append(f"k {k} vs {ref['basis']['k']}")
+    # Free of the basis freedom (signs, rotations inside near-degenerate subspaces), so checked to tight tolerances in every
+    # case: the coefficients are the projections on the DEVICE's own (rounded) basis, and the device's payloads are
+    # what the reference quantizer (the C oracle) makes of the device's own c_low, bit for bit.
+    if r > 0:
+        Uh, Ul, mu = plan.basis_tensors(0, k, r, D)
+        U = torch.cat([Uh, Ul], dim=1).double().cpu().numpy() if (k > 0 and r > k) else \
+            (Uh if k > 0 else Ul).double().cpu().numpy()
+        mu32 = mu.flatten().cpu().numpy() if mu is not None else None
+        for t in range(N):
+            x32 = deltas[t].numpy() - mu32 if mu32 is not None else deltas[t].numpy()      # fp32, like compress.py:44
+            want = U.T @ x32.astype(np.float64)
+            got = sm.coef[0, t, :r].astype(np.float64)
+            # column i is U_i = Tc v_i / sigma_i formed in fp32: its own error is ~eps32 sigma_0 / sigma_i, and the
+            # coefficient (closed form sigma_i v_i + the fp16-rounding correction) differs from the explicit projection
+            # on the stored column by that much of |x| (seed 5001 case 805: sigma_30 = 5e-4 sigma_0, 3e-5 |x|)
+            sg = np.maximum(sm.sigma[0, :r].astype(np.float64), 1e-30)
+            tol = float(np.linalg.norm(x32)) * np.minimum(1e-5 + 3e-7 * sg[0] / sg, 1e-3) + 1e-12
+            if mu32 is not None:      # the rows of T - mean sum to a few ulp(mean), not to 0; the device removes that
+                tol = tol + 2.4e-7 * float(np.linalg.norm(mu32))      # component (1 / sqrt(N) is deflated), a GEMV keeps it
+            if np.isfinite(want).all() and not np.all(np.abs(got - want) <= tol):
+                bad_i = int(np.argmax(np.abs(got - want) / tol))
+                msgs.append(f"projection on the device's basis: task {t} column {bad_i}, |dc| "
+                            f"{abs(got[bad_i] - want[bad_i]):.2e} (tol {tol[bad_i]:.1e})")
+                break
+            if r > k:
+                art = sq.pipeline.task_artifact(plan, sm, 0, t)["c_low_quant"]
+                oq = orc.rtvq_quantize(sm.coef[0, t, k:r].copy(), bits, stages)
+                same = len(art["payloads"]) == oq["codes"].shape[0]
+                for s_, pa in enumerate(art["payloads"]):
+                    if not same:
+                        break
+                    qa = pa["quantized"].numpy().reshape(-1)
+                    sa = np.array([pa["scale"].item(), pa["zero_point"].item()], dtype=np.float32)
+                    sb = np.array([oq["scale"][s_], oq["zero_point"][s_]], dtype=np.float32)
+                    # (a NaN is a NaN: x86 and gfx950 differ in the sign bit of the default NaN -- the F4 cases)
+                    same = np.array_equal(qa, oq["codes"][s_]) and bool(np.all(
+                        (sa.view(np.uint32) == sb.view(np.uint32)) | (np.isnan(sa) & np.isnan(sb))))
+                if not same:
+                    msgs.append(f"quantizer on the device's own c_low: task {t} differs from the reference quantizer")
+                    break
+    # the span of the high-energy columns is unique when a gap separates sigma_{k-1} from sigma_k: principal angles between
+    # the reference's U_high and the device's (both fp16-rounded: cosines within ~1e-3 of 1)
+    if k == ref["basis"]["k"] and 0 < k < r and real[k - 1] and S_ref[k - 1] > 1.05 * S_ref[k] and D > k:
+        Ud = plan.basis_tensors(0, k, r, D)[0].float().cpu().numpy().astype(np.float64)
+        Ur = ref["basis"]["U_high"].float().numpy().astype(np.float64)
+        if np.isfinite(Ud).all() and np.isfinite(Ur).all():
+            gap = float(S_ref[k - 1] / S_ref[k]) - 1.0
+            cosines = np.linalg.svd(Ur.T @ Ud, compute_uv=False)
+            # fp32 SVDs leave ~eps32 / gap of mixing between the two sides of the gap, fp16 rounding 1e-3 of norm
+            if cosines.min() < 1.0 - 2e-3 - min(1e-5 / gap, 0.5):
+                msgs.append(f"span of U_high: smallest principal cosine {cosines.min():.6f} (gap {gap:.2e})")
     if k == ref["basis"]["k"] and r - k > 2:
         U_high, U_low, mean = plan.basis_tensors(0, k, r, D)
         quant = sq.RTVQQuantizer(bits, stages)
