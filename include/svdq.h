@@ -405,7 +405,7 @@ int svdq_recon_error(const void *u_high_dev, const void *u_low_dev, int32_t u_fp
  *       out[p][d] = sum_s share[s] * (((U_high c_s,high + U_low c_s,low)[d] + mean[d]) * scale[p])  (+ base[p][d])
  *     set_share_dev: NULL (n_sets = 1: no weighting) or float [n_sets] / [P][n_sets], the clusters' shares renormalised
  *     as apply_weights_to_tensors does (weighting.py:332-372), < 0 = set absent; n_sets <= 8.
- *     scale_dev: NULL or float [P] (noise_shrink of the noise regions, merge.py:270); base_ptrs_dev: NULL or [P] base
+ *     scale_dev: NULL or float [P] (noise_shrink of the noise regions, merge.py:284); base_ptrs_dev: NULL or [P] base
  *     tensors (then out = base + delta); out_ptrs_dev [P] fp32 outputs of rows[p] elements (compacted rows for masked
  *     parameters: svdq_mask_expand scatters them).  A parameter's rows are the bits svdq_reconstruct gives.
  *   svdq_merge = both; work_dev: svdq_merge_work_bytes(plan, n_sets).

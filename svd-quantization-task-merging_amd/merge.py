@@ -52,7 +52,7 @@ def reconstruct_from_coefficients(avg_c_high: torch.Tensor, avg_c_low: torch.Ten
 
 
 def _reconstruct(avg_c_high, avg_c_low, U_high, U_low, mean, scale: float) -> torch.Tensor:
-    """``scale`` folds the ``* noise_shrink`` of merge.py:270 into the same streaming pass."""
+    """``scale`` folds the ``* noise_shrink`` of merge.py:284 into the same streaming pass."""
     lib = nat.lib()
     dev = resolve_device(U_high.device if U_high.is_cuda else "cuda")
     D = U_high.shape[0] if U_high.dim() == 2 else U_low.shape[0]
