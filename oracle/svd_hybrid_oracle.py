@@ -20,6 +20,7 @@ What is restated (paths relative to /root/reference):
   R10-R12 quantizer           src/svd_hybrid/rtvq.py:4-139        (C restatement: rtvq_oracle.c)
   R13 loops / dict layout     src/svd_hybrid/compress.py:59-207
   R14 reconstruction          src/svd_hybrid/merge.py:61-194, mask_loader.py:712-763
+  f2  per-task error tuple    src/svd_hybrid/diagnostics.py:72-117, 186-215 (no mean added back)
 
 Third-party arithmetic: the SVD itself is LAPACK ``gesdd`` reached through
 ``torch.linalg.svd`` (MKL in this image's torch 2.10.0 CPU build); the reference pins
@@ -316,6 +317,36 @@ def reconstruct(c_high: torch.Tensor, c_low: torch.Tensor, U_high: torch.Tensor,
     if mean is not None:
         out = out + mean.squeeze().float()
     return out
+
+
+DIAG_KEYS = ("absolute_error", "relative_error", "max_absolute_error", "mean_absolute_error", "original_norm",
+             "reconstructed_norm")
+
+
+def reconstruction_error(original: torch.Tensor, reconstructed: torch.Tensor) -> Dict[str, float]:
+    """diagnostics.py:72-117, in the dtype of the inputs (the reference runs it on fp32 tensors)."""
+    error = original - reconstructed
+    original_norm = original.norm().item()
+    error_norm = error.norm().item()
+    return {"absolute_error": error_norm,
+            "relative_error": error_norm / original_norm if original_norm > 1e-10 else 0,
+            "max_absolute_error": error.abs().max().item(),
+            "mean_absolute_error": error.abs().mean().item(),
+            "original_norm": original_norm,
+            "reconstructed_norm": reconstructed.norm().item()}
+
+
+def parameter_task_diagnostics(x: torch.Tensor, U_high: torch.Tensor, U_low: torch.Tensor, c_high: torch.Tensor,
+                               c_low: torch.Tensor, dtype=torch.float32, mean: Optional[torch.Tensor] = None) -> Dict[str, float]:
+    """diagnostics.py:186-215 for one (parameter, task): ``U_high.float() @ c_high + U_low.float() @ c_low`` -- the mean is
+    NOT added back (``mean`` exists for the add_mean extension of the plan-level kernel) -- compared with the
+    original (masked) delta.  ``dtype`` float32 is the reference's arithmetic; float64 evaluates the same formula on the
+    same stored numbers without the fp32 rounding of the matrix products and sums (the checker of the HIP kernels, whose
+    sums run in fp64)."""
+    rec = U_high.to(dtype) @ c_high.to(dtype) + U_low.to(dtype) @ c_low.to(dtype)
+    if mean is not None:
+        rec = rec + mean.reshape(-1).to(dtype)
+    return reconstruction_error(x.reshape(-1).to(dtype), rec)
 
 
 def compress_parameter(deltas: Sequence[torch.Tensor], energy_threshold: float = 0.90,

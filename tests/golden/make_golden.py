@@ -25,6 +25,9 @@ Fixture families (all .npz, loadable with allow_pickle=False):
   pipeline.npz    cli.py Step 4 + Step 5 loop bodies over 3 layers x 4 tasks
                   (construct_masked_basis + compress_all_parameters), dict layout + numbers
   merge.npz       merge_all_parameters + apply_merged_deltas (merge.py:304-552), 6 tasks, weighted
+  diag.npz        compute_all_diagnostics' per-(parameter, task) error tuples TOGETHER WITH the artifacts they were
+                  computed from (the reference's own U_high / U_low / c_high_fp16 / dequantized c_low and the masked
+                  originals), so a checker can be pinned on them with no basis freedom left (diagnostics.py:186-215)
   tvq.npz         TaskVector / compute_task_vector and the QuantizedTaskVector family
                   (task_vectors.py, quantization_utils.py) on a toy state dict x 3 tasks
   cluster.npz     cluster_tasks / compute_cluster_statistics (clustering.py), compute_weights family
@@ -488,6 +491,94 @@ def gen_merge():
 
 
 
+def _diag_case(prefix, shapes, tasks, cfg, masks, seed0, out):
+    """cli.py Step 4 + 5 + diagnostics of the reference on a toy model; stores, per parameter, what
+    compute_parameter_diagnostics (diagnostics.py:120-231) read -- the masked originals, the (fp16-cast) basis, every task's
+    c_high_fp16 and dequantized c_low -- and the six numbers it returned for every task."""
+    task_vectors = {t: {} for t in tasks}
+    for pi, (pname, shp) in enumerate(sorted(shapes.items())):
+        for t, d in zip(tasks, synthetic_deltas(int(np.prod(shp)), len(tasks), seed0 + pi)):
+            task_vectors[t][pname] = d.view(shp)
+    bases = {}
+    for pname in sorted(shapes):
+        mask = masks.get(pname)
+        md, ud = [], []
+        for t in tasks:
+            delta = task_vectors[t][pname]
+            if mask is not None and mask.shape == delta.shape:
+                md.append(ref_masks.apply_mask_to_tensor(delta, mask))
+                ud.append(ref_masks.get_unmasked_portion(delta, mask))
+            else:
+                md.append(delta.flatten())
+        basis = ref_basis.construct_masked_basis(md, ud if ud else None, energy_threshold=cfg.svd_energy_threshold,
+                                                 max_rank=cfg.svd_max_rank, center=cfg.svd_center, device="cpu",
+                                                 include_noise=cfg.svd_include_noise)
+        if cfg.svd_fp16:
+            for region in ("masked", "noise"):
+                if basis.get(region) is not None:
+                    basis[region]["U_high"] = basis[region]["U_high"].half()
+                    basis[region]["U_low"] = basis[region]["U_low"].half()
+        bases[pname] = basis
+    compressed = ref_compress.compress_all_parameters(task_vectors, masks, bases, cfg, device="cpu")
+    diag = ref_diag.compute_all_diagnostics(task_vectors, compressed, bases, masks, cfg, device="cpu")
+    quant = ref_rtvq.RTVQQuantizer(cfg.svd_low_bits, cfg.svd_rtvq_stages)
+    keys = ("absolute_error", "relative_error", "max_absolute_error", "mean_absolute_error", "original_norm",
+            "reconstructed_norm")
+    for pname in sorted(shapes):
+        bm = bases[pname]["masked"]
+        assert bm["N"] - bm["k"] >= 3, (pname, bm["k"])          # finite quantizer (SURVEY F4)
+        mask = masks.get(pname)
+        xs, chs, cls, met = [], [], [], []
+        for t in tasks:
+            delta = task_vectors[t][pname]
+            xs.append((ref_masks.apply_mask_to_tensor(delta, mask) if mask is not None else delta.flatten()).numpy())
+            art = compressed[pname][t]["masked"]
+            chs.append(art["c_high_fp16"].numpy())
+            cls.append(quant.dequantize(art["c_low_quant"]).float().numpy().reshape(-1))
+            e = diag["per_parameter"][pname]["reconstruction_errors"][t]
+            met.append([float(e[k]) for k in keys])
+        out[f"{prefix}__x__{pname}"] = np.stack(xs)
+        out[f"{prefix}__U_high__{pname}"] = bm["U_high"].numpy()
+        out[f"{prefix}__U_low__{pname}"] = bm["U_low"].numpy()
+        out[f"{prefix}__c_high_fp16__{pname}"] = np.stack(chs)
+        out[f"{prefix}__c_low_deq__{pname}"] = np.stack(cls)
+        out[f"{prefix}__metrics__{pname}"] = np.array(met, dtype=np.float64)
+        if bm["mean"] is not None:
+            out[f"{prefix}__mean__{pname}"] = bm["mean"].squeeze(1).numpy()
+        if mask is not None:
+            out[f"{prefix}__mask__{pname}"] = mask.numpy()
+    out[f"{prefix}__params"] = np.array(sorted(shapes))
+    out[f"{prefix}__tasks"] = np.array(tasks)
+
+
+def gen_diag():
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    # A: merge.npz's configuration (fp16 basis, centred: Q1 makes the error ~ ||mean|| / ||x||), one masked parameter
+    shapes = {"a.weight": (96, 64), "a.bias": (96,), "b.weight": (80, 40)}
+    cfg = types.SimpleNamespace(svd_low_bits=4, svd_rtvq_stages=2, svd_include_noise=False, svd_min_mask_size=10,
+                                svd_energy_threshold=0.9, svd_max_rank=2, svd_center=True, svd_fp16=True,
+                                svd_noise_shrink=0.5, svd_mask_strategy="union", svd_weighting="uniform")
+    masks = {"b.weight": torch.rand(shapes["b.weight"], generator=g) > 0.4}
+    _diag_case("A", shapes, [f"T{i}" for i in range(6)], cfg, masks, 300, out)
+    # B: 20 tasks, fp32 basis, NOT centred (the error is then the small quantization / rounding error itself: the case in
+    # which a wrong L1 / L-infinity or a dropped column shows), ragged sizes, one masked parameter
+    shapes = {"w": (70, 73), "v": (257,), "e": (1, 3001)}
+    cfg = types.SimpleNamespace(svd_low_bits=4, svd_rtvq_stages=2, svd_include_noise=False, svd_min_mask_size=10,
+                                svd_energy_threshold=0.9, svd_max_rank=None, svd_center=False, svd_fp16=False,
+                                svd_noise_shrink=0.5, svd_mask_strategy="union", svd_weighting="uniform")
+    masks = {"w": torch.rand(shapes["w"], generator=g) > 0.3}
+    _diag_case("B", shapes, [f"T{i:02d}" for i in range(20)], cfg, masks, 700, out)
+    # C: 12 tasks, fp16 basis, not centred, 8-bit x 1 stage
+    shapes = {"m": (33, 129), "s": (513,)}
+    cfg = types.SimpleNamespace(svd_low_bits=8, svd_rtvq_stages=1, svd_include_noise=False, svd_min_mask_size=10,
+                                svd_energy_threshold=0.9, svd_max_rank=None, svd_center=False, svd_fp16=True,
+                                svd_noise_shrink=0.5, svd_mask_strategy="union", svd_weighting="uniform")
+    _diag_case("C", shapes, [f"T{i:02d}" for i in range(12)], cfg, {}, 900, out)
+    out["cases"] = np.array(["A", "B", "C"])
+    save("diag.npz", **out)
+
+
 # ------------------------------------------------------------------------------- artifact files (f3)
 def _tree(o):
     """Structure of a saved object: key trees, tensor dtypes / shapes, python types (no values)."""
@@ -934,6 +1025,7 @@ if __name__ == "__main__":
     gen_masks()
     gen_pipeline()
     gen_merge()
+    gen_diag()
     gen_storage()
     gen_cluster()
     gen_tvq()

@@ -82,3 +82,35 @@ def artifact_manifest(root):
             elif f.endswith(".json"):
                 man[rel] = _json_tree(json.load(open(full)))
     return man
+
+
+def diag_fp32_bound(U_high, U_low, c_high, c_low, x):
+    """Forward-error bound of the fp32 arithmetic in ``U_high.float() @ c_high + U_low.float() @ c_low`` (reference
+    diagnostics.py:210-212) for each of the six error numbers: every element of the reconstruction carries at most
+    ``(r + 2) * 2^-24 * (|U| |c|)_i`` of rounding whatever order an fp32 implementation sums the r products in (the
+    reference's BLAS, a chain of fmas, an MFMA), and the error vector inherits it.  Measured on tests/golden/diag.npz:
+    the reference's OWN fp32 numbers sit up to 7e-5 (max_absolute_error, uncentred runs whose error is ~1e-3 of the
+    tensor) from the fp64 evaluation of the same formula on the same stored numbers -- inside this bound, far outside
+    a flat 1e-5.  Returns {key: absolute tolerance against the fp64 evaluation}."""
+    import torch
+    A = torch.cat([U_high.double().abs(), U_low.double().abs()], dim=1) @ torch.cat(
+        [c_high.double().abs().reshape(-1), c_low.double().abs().reshape(-1)])
+    r = U_high.shape[1] + U_low.shape[1]
+    g = (r + 2) * 2.0 ** -24
+    xn = float(x.double().norm())
+    l2, linf, l1 = float(A.norm()) * g, float(A.max()) * g if A.numel() else 0.0, float(A.mean()) * g if A.numel() else 0.0
+    return {"absolute_error": l2, "relative_error": l2 / xn if xn > 1e-10 else 0.0, "max_absolute_error": linf,
+            "mean_absolute_error": l1, "original_norm": 0.0, "reconstructed_norm": l2}
+
+
+def diag_check(got, x, U_high, U_low, c_high, c_low, what="", mean=None, slack=1.0):
+    """All six numbers of one (parameter, task) against diagnostics.py:186-215 evaluated in fp64 on the SAME stored
+    artifacts (no basis freedom): relative 2e-6 (the fp32 conversion of the norms the kernels report) plus the fp32
+    bound above."""
+    from oracle import svd_hybrid_oracle as orc
+    import torch
+    want = orc.parameter_task_diagnostics(x, U_high, U_low, c_high, c_low, dtype=torch.float64, mean=mean)
+    tol = diag_fp32_bound(U_high, U_low, c_high, c_low, x)
+    for key in orc.DIAG_KEYS:
+        g, w = float(got[key]), float(want[key])
+        assert abs(g - w) <= 2e-6 * abs(w) + slack * tol[key] + 1e-30, (what, key, g, w, tol[key])

@@ -238,6 +238,32 @@ def test_mask_reference_kats():
 
 
 # ------------------------------------------------------------------------------- reconstruction
+def test_parameter_diagnostics_vs_reference_artifacts():
+    """The oracle's restatement of diagnostics.py:72-117,186-215 on the reference's OWN artifacts (diag.npz holds the
+    basis, coefficients and masked originals the reference computed its numbers from): in fp32 it is the reference's
+    arithmetic (equal to the last bit of the printed doubles); in fp64 it stays inside the stated fp32 forward-error
+    bound -- the bound the GPU tests then hold the HIP kernels to, on the kernels' own artifacts."""
+    from helpers import diag_fp32_bound
+    g = load_golden("diag.npz")
+    worst = 0.0
+    for c in g["cases"]:
+        for p in g[f"{c}__params"]:
+            X = torch.from_numpy(g[f"{c}__x__{p}"])
+            Uh, Ul = torch.from_numpy(g[f"{c}__U_high__{p}"]), torch.from_numpy(g[f"{c}__U_low__{p}"])
+            ch, cl = torch.from_numpy(g[f"{c}__c_high_fp16__{p}"]).float(), torch.from_numpy(g[f"{c}__c_low_deq__{p}"])
+            M = g[f"{c}__metrics__{p}"]
+            assert Uh.shape[0] == X.shape[1] and Uh.shape[1] + Ul.shape[1] == X.shape[0]
+            for t in range(X.shape[0]):
+                m32 = orc.parameter_task_diagnostics(X[t], Uh, Ul, ch[t], cl[t])
+                m64 = orc.parameter_task_diagnostics(X[t], Uh, Ul, ch[t], cl[t], dtype=torch.float64)
+                tol = diag_fp32_bound(Uh, Ul, ch[t], cl[t], X[t])
+                for j, key in enumerate(orc.DIAG_KEYS):
+                    assert m32[key] == M[t, j], (c, p, t, key)
+                    assert abs(m64[key] - M[t, j]) <= 2e-6 * abs(M[t, j]) + tol[key], (c, p, t, key)
+                    worst = max(worst, abs(m64[key] - M[t, j]) / abs(M[t, j]))
+    assert 1e-5 < worst < 2e-4      # the reference's fp32 numbers ARE further than 1e-5 from fp64 (max_absolute_error)
+
+
 def test_reconstruction_identity_kat():
     """reference tests/test_mean_handling.py:206-312: reconstruct == U_h c_h + U_l c_l (+mean)
     and projection round trip, to 1e-5, for a random orthonormal U."""
