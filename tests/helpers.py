@@ -84,7 +84,7 @@ def artifact_manifest(root):
     return man
 
 
-def diag_fp32_bound(U_high, U_low, c_high, c_low, x):
+def diag_fp32_bound(U_high, U_low, c_high, c_low, x, mean=None):
     """Forward-error bound of the fp32 arithmetic in ``U_high.float() @ c_high + U_low.float() @ c_low`` (reference
     diagnostics.py:210-212) for each of the six error numbers: every element of the reconstruction carries at most
     ``(r + 2) * 2^-24 * (|U| |c|)_i`` of rounding whatever order an fp32 implementation sums the r products in (the
@@ -96,6 +96,9 @@ def diag_fp32_bound(U_high, U_low, c_high, c_low, x):
     A = torch.cat([U_high.double().abs(), U_low.double().abs()], dim=1) @ torch.cat(
         [c_high.double().abs().reshape(-1), c_low.double().abs().reshape(-1)])
     r = U_high.shape[1] + U_low.shape[1]
+    if mean is not None:      # the add_mean extension rounds once more, at the size of |rec| + |mean|
+        A = A + mean.double().abs().reshape(-1)
+        r += 1
     g = (r + 2) * 2.0 ** -24
     xn = float(x.double().norm())
     l2, linf, l1 = float(A.norm()) * g, float(A.max()) * g if A.numel() else 0.0, float(A.mean()) * g if A.numel() else 0.0
@@ -110,7 +113,7 @@ def diag_check(got, x, U_high, U_low, c_high, c_low, what="", mean=None, slack=1
     from oracle import svd_hybrid_oracle as orc
     import torch
     want = orc.parameter_task_diagnostics(x, U_high, U_low, c_high, c_low, dtype=torch.float64, mean=mean)
-    tol = diag_fp32_bound(U_high, U_low, c_high, c_low, x)
+    tol = diag_fp32_bound(U_high, U_low, c_high, c_low, x, mean=mean)
     for key in orc.DIAG_KEYS:
         g, w = float(got[key]), float(want[key])
         assert abs(g - w) <= 2e-6 * abs(w) + slack * tol[key] + 1e-30, (what, key, g, w, tol[key])
