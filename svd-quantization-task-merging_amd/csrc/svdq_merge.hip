@@ -432,17 +432,30 @@ struct DiagPart {
     double se, sx, sr, sa, mx;
 };
 
-// A workgroup of W = ceil(N / 8) wavefronts per work unit; wavefront w owns tasks 8 w .. 8 w + 7 for ALL rows, so its
-// running sums (5 per task) stay in registers.  A block is up to 256 rows; lane l owns rows l, 64 + l, 128 + l, 192 + l.
-// Software pipeline, one block deep: while block b is computed from LDS, the loads of block b + 1 are in flight into
-// registers -- its N deltas (dword loads, 256 contiguous bytes per task and instruction), its run of basis rows (16-byte
-// loads, shared by the W wavefronts) and, in walk mode, its mask bytes.  Per block: registers -> LDS (deltas to the
-// wavefront's own X[task][row] strip, basis rows to one of two shared buffers), one barrier, issue the next block's
-// loads, compute.  The per-row arithmetic is k_recon_error's: fp32 fma chains over the columns, hi + lo (+ mean), fp64 sums.
-// WALK: the block is a chunk of 256 SOURCE rows of a masked region (k_merge_expand's walk); selected rows are written
-// to X at their rank, so the compute phase is the same loop over `count` compacted rows.  The next chunk's basis run
-// starts where this one ends; its length is not known before its mask is, so 256 rows (clamped to the unit) are fetched.
-#define DG_XS (SVDQ_BLK_ROWS + 64)      // X row: 256 rows + one dump slot per lane (unselected rows are written there: no branch)
+// One wavefront per work unit.  The reconstruction tile rec[row][task] = sum_c U[row][c] C[c][task] is formed on the
+// matrix pipe (v_mfma_f32_16x16x4_f32: rows on M, tasks on N, basis columns on K), the vector ALU only sees the
+// epilogue: e = x - rec, packed fmas for the three sums of squares, |e| into the L1 sum and the maximum.  In the result
+// layout lane l holds rows 4 (l >> 4) .. + 3 of the 16-row tile for ONE task (l & 15), so a lane's running sums belong to
+// one task per 16-task tile -- 5 sums per lane instead of 5 N.
+//   block   = RB rows (256 for N <= 8, 128 above): global -> registers one block ahead (the N deltas with vector loads,
+//             1 KiB / 512 B contiguous per task and instruction; the run of basis rows with 16-byte loads), registers -> LDS
+//             (X[task][row] strips, the two basis parts row-major as they are stored), wave-level fence, issue the next
+//             block's loads, compute from LDS.
+//   K slots : slot (step s, lane group g = l >> 4) carries one basis column; the SAME map is used for the A operand (U)
+//             and the B operand (C, in registers for the whole unit), so any map is a valid contraction.  High part: column
+//             KSH g + s (KSH = ceil(k / 4) steps), low part: column KSL g + (s - KSH): a lane's columns of a part are
+//             consecutive elements of its row, each step one ds_read at a per-step address that advances by a constant
+//             per tile.  Slots past a part's columns carry C = 0 (their U operand is a finite staged value).
+//   N <= 8  : PACK2 -- two 16-row sets share one tile: K slots 0..7 carry set A's columns, 8..15 set B's; result columns
+//             0..7 are the tasks for set A's rows, 8..15 the same tasks for set B's (C is zero in the off-diagonal
+//             blocks), so no result register is idle.
+//   N > 16  : two task tiles per row tile (the A operand is shared).
+// Sums: fp32 inside a block (two chains of <= 16 terms per lane), fp64 across blocks; rows past the block's count take
+// the masked form of the tile (exact zeros).  WALK: the block is a chunk of RB SOURCE rows of a masked region
+// (k_merge_expand's walk); selected rows are written to X at their rank, so the compute phase is the same loop over
+// `count` compacted rows; the next chunk's basis run starts where this one ends, RB rows (clamped to the unit) are fetched.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) f32x2 mg_gf32x2;
 
 struct UStage {      // where a block's staged basis rows sit (wave-uniform)
     int nvh, nv;     // 16-byte vectors of the U_high part, of both parts
@@ -463,30 +476,48 @@ __device__ __forceinline__ UStage ustage_plan(int64_t c0, int nr, int k, int nl)
     return u;
 }
 
-template <int W, int TPW, bool U16, bool WALK>
-__global__ __launch_bounds__(64 * W, (TPW == 4 ? 4 : 2)) void k_diag(const SvdqParam *__restrict__ params,
-                                                  const SvdqUnit *__restrict__ units,
-                                                  const float *const *__restrict__ ptrs,
-                                                  const uint8_t *const *__restrict__ mask_ptrs,
-                                                  const int64_t *__restrict__ ustart,
-                                                  const int64_t *__restrict__ rows_dev, int NT,
-                                                  const int32_t *__restrict__ k_in, const int32_t *__restrict__ r_in,
-                                                  const uint8_t *__restrict__ basis, const float *__restrict__ meanbuf,
-                                                  int add_mean, const float *__restrict__ ctask /* [P][N][N] */,
-                                                  DiagPart *__restrict__ part /* [n_units][N] */) {
+__device__ __forceinline__ float lds_u(const uint8_t *base, int byte_off, __half) {
+    return __half2float(*reinterpret_cast<const __half *>(base + byte_off));
+}
+__device__ __forceinline__ float lds_u(const uint8_t *base, int byte_off, float) {
+    return *reinterpret_cast<const float *>(base + byte_off);
+}
+
+template <int NTP, int RPL_, bool PACK2> struct DiagGeom {
+    static constexpr int RPL = RPL_;                     // rows per lane and block (4 with PACK2)
+    static constexpr int RB = 64 * RPL;                  // rows per block
+    static constexpr int TT = NTP > 16 ? 2 : 1;          // 16-task tiles
+    static constexpr int TROWS = PACK2 ? 32 : 16;        // rows per MFMA tile
+    static constexpr int KMAX = PACK2 ? 4 : NTP / 4 + 1; // K steps of 4 slots
+};
+__host__ __device__ constexpr int diag_xs(int rb, bool walk) { return rb + 4 + (walk ? 64 : 0); }   // X strip stride (floats)
+
+template <bool B> struct DiagBool { static constexpr bool value = B; };
+
+// FULL: the plan has exactly NTP tasks -- no "task t is real" tests (each one is a scalar-register pair the compiler
+// keeps across the loop; with twenty of them the task pointers are pushed out of the scalar registers)
+template <int NTP, int RPL_, bool PACK2, bool FULL, bool U16, bool WALK>
+__global__ __launch_bounds__(64) void k_diag(const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
+                                             const float *const *__restrict__ ptrs,
+                                             const uint8_t *const *__restrict__ mask_ptrs,
+                                             const int64_t *__restrict__ ustart, const int64_t *__restrict__ rows_dev,
+                                             int NT, const int32_t *__restrict__ k_in, const int32_t *__restrict__ r_in,
+                                             const uint8_t *__restrict__ basis, const float *__restrict__ meanbuf,
+                                             int add_mean, const float *__restrict__ ctask /* [P][N][N] */,
+                                             DiagPart *__restrict__ part /* [n_units][N] */) {
     using T = typename UElem<U16>::type;
+    using G = DiagGeom<NTP, RPL_, PACK2>;
+    static_assert(!PACK2 || RPL_ == 4, "PACK2 tiles are 32 rows of a 256-row block");
     constexpr int ES = U16 ? 2 : 4;
-    // 16-byte vectors of one block's basis rows per thread: 256 rows x 8 W columns x ES bytes over 64 W threads, + ends
-    constexpr int SV = (SVDQ_BLK_ROWS * TPW * ES / 16) / 64 + 1;      // 16 n ES + 4 vectors over 64 W threads, n <= TPW W
+    constexpr int RPL = G::RPL, RB = G::RB, TT = G::TT, TROWS = G::TROWS, KMAX = G::KMAX;
+    constexpr int XSD = diag_xs(RB, WALK);
+    constexpr int SV = (RB * NTP * ES / 16 + 2 + 63) / 64;      // 16-byte vectors of one block's basis rows per lane
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = NT, u = blockIdx.x;
-    const int ubytes = (int)svdq_align_up((int64_t)SVDQ_BLK_ROWS * n * ES + 64, 16);
-    uint8_t *Ubuf = lds_raw;                                                  // two buffers
-    float *Cw = reinterpret_cast<float *>(lds_raw + 2 * ubytes) + (size_t)w * n * TPW;   // [column][8 tasks] per wave
-    float *Xw = reinterpret_cast<float *>(lds_raw + 2 * ubytes) + (size_t)W * n * TPW +
-                (size_t)w * (TPW + 1) * DG_XS;                             // [8 tasks + mean][256 rows + dump] per wave
-    const int t0 = w * TPW;
-    const int nt = (n - t0 < TPW) ? (n - t0) : TPW;      // tasks of this wave (>= 1: W = ceil(N / 8))
+    const int lane = threadIdx.x, n = FULL ? NTP : NT, u = blockIdx.x;
+    const int g = lane >> 4, col = lane & 15;
+    const int ubytes = (int)svdq_align_up((int64_t)RB * n * ES + 48, 16);
+    uint8_t *Ubuf = lds_raw;
+    float *X = reinterpret_cast<float *>(lds_raw + ubytes);      // [NTP tasks + mean][XSD]
     const SvdqUnit ud = units[u];
     const int p = ud.param;
     const SvdqParam pd = params[p];
@@ -494,27 +525,54 @@ __global__ __launch_bounds__(64 * W, (TPW == 4 ? 4 : 2)) void k_diag(const SvdqP
     int64_t cpos = ud.row0;
     int64_t cend = ud.row0 + ud.nrows;
     if (cend > D) cend = D;
-    double se[TPW], sx[TPW], sr[TPW], sa[TPW];
-    float mx[TPW];
+    // the task whose column this lane holds in each task tile (PACK2: both row sets carry tasks 0..7)
+    int task[TT];
 #pragma unroll
-    for (int a = 0; a < TPW; ++a) {
-        se[a] = sx[a] = sr[a] = sa[a] = 0.0;
-        mx[a] = 0.f;
+    for (int tt = 0; tt < TT; ++tt) task[tt] = PACK2 ? (col & 7) : col + 16 * tt;
+    double se[TT], sx[TT], sr[TT], sa[TT];
+    float mx[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        se[tt] = sx[tt] = sr[tt] = sa[tt] = 0.0;
+        mx[tt] = 0.f;
     }
-    if (cpos < cend) {      // workgroup-uniform
+    if (cpos < cend) {      // wave-uniform
         const int k = k_in[p], r = r_in[p], nl = r - k;
-        for (int e = lane; e < n * TPW; e += 64) {      // this wave's coefficient table, [column][task]
-            const int c = e / TPW, a = e % TPW;
-            Cw[e] = (a < nt) ? ctask[(size_t)p * n * n + (size_t)(t0 + a) * n + c] : 0.f;
-        }
+        const int KSH = PACK2 ? 0 : (k + 3) >> 2, KSL = PACK2 ? 0 : (nl + 3) >> 2;
+        const int KT = PACK2 ? 4 : KSH + KSL;
+        // basis column of K slot (step s, this lane's group), -1 = the slot is idle
+        auto slot_col = [&](int s) -> int {
+            if constexpr (PACK2) {
+                const int c = 2 * g + (s & 1);
+                return c < r ? c : -1;
+            } else {
+                if (s < KSH) {
+                    const int c = KSH * g + s;
+                    return c < k ? c : -1;
+                }
+                const int c = KSL * g + (s - KSH);
+                return (s < KT && c < nl) ? k + c : -1;
+            }
+        };
+        // B operand: the coefficients of the lane's task(s), one register per step, for the whole unit
+        float creg[TT][KMAX];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                const int c = slot_col(s);
+                bool on = c >= 0 && task[tt] < n;
+                if constexpr (PACK2) on = on && ((s >> 1) == (col >> 3));      // set A's slots feed columns 0..7 only
+                creg[tt][s] = on ? ctask[(size_t)p * n * n + (size_t)task[tt] * n + c] : 0.f;
+            }
         const uint8_t *slab = basis + pd.slab_off;
         const uint8_t *gUh = slab;
         const uint8_t *gUl = slab + svdq_align_up(D * (int64_t)k * ES, 256);
         mg_gfloat *gmean = (add_mean && meanbuf) ? (mg_gfloat *)(meanbuf + pd.mean_off) : nullptr;
         mg_gbyte *gmask = WALK ? (mg_gbyte *)mask_ptrs[p] : nullptr;
-        mg_gfloat *dp[TPW];
+        mg_gfloat *dp[NTP];
 #pragma unroll
-        for (int a = 0; a < TPW; ++a) dp[a] = (mg_gfloat *)ptrs[(size_t)p * n + t0 + (a < nt ? a : 0)];
+        for (int t = 0; t < NTP; ++t) dp[t] = (mg_gfloat *)ptrs[(size_t)p * n + (t < n ? t : 0)];
         int64_t src = cpos, src_hi = cend;      // plain: source rows = compacted rows
         int inv = 0;
         if constexpr (WALK) {
@@ -524,184 +582,223 @@ __global__ __launch_bounds__(64 * W, (TPW == 4 ? 4 : 2)) void k_diag(const SvdqP
             inv = rg.inv;
         }
         // ---- the loads of one block into registers
-        float xpf[TPW][4] = {}, mpf[4];
-        unsigned mkpf[4];
+        float xpf[NTP][RPL] = {}, mpf[RPL] = {};
+        unsigned mkpf[RPL] = {};
         f32x4 ureg[SV];
-        UStage us;
         auto prefetch = [&](int64_t s0, int64_t c0) {
-            const int64_t r0 = s0 + lane;
-            if (s0 + SVDQ_BLK_ROWS <= src_hi) {      // the whole chunk is in range (all but a unit's last): plain loads
+            if constexpr (WALK) {      // lane l owns source rows s0 + 64 e + l
+                const int64_t r0 = s0 + lane;
+                if (s0 + RB <= src_hi) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if constexpr (WALK) mkpf[e] = (unsigned)gmask[r0 + 64 * e];
+                    for (int e = 0; e < RPL; ++e) mkpf[e] = (unsigned)gmask[r0 + 64 * e];
 #pragma unroll
-                for (int a = 0; a < TPW; ++a)
-                    if (a < nt) {      // wave-uniform
+                    for (int t = 0; t < NTP; ++t)
+                        if (t < n) {      // wave-uniform
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) xpf[a][e] = dp[a][r0 + 64 * e];
+                            for (int e = 0; e < RPL; ++e) xpf[t][e] = dp[t][r0 + 64 * e];
+                        }
+                } else {
+                    bool in[RPL];
+#pragma unroll
+                    for (int e = 0; e < RPL; ++e) {
+                        in[e] = r0 + 64 * e < src_hi;
+                        mkpf[e] = in[e] ? (unsigned)gmask[r0 + 64 * e] : 0x100u;
                     }
-            } else {
-                bool in[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    in[e] = r0 + 64 * e < src_hi;
-                    if constexpr (WALK) mkpf[e] = in[e] ? (unsigned)gmask[r0 + 64 * e] : 0x100u;
+                    for (int t = 0; t < NTP; ++t)
+                        if (t < n) {
+#pragma unroll
+                            for (int e = 0; e < RPL; ++e) xpf[t][e] = in[e] ? dp[t][r0 + 64 * e] : 0.f;
+                        }
                 }
+            } else {                   // lane l owns rows s0 + RPL l .. + RPL - 1: one vector load per task
+                const int64_t r0 = s0 + RPL * lane;
+                if (s0 + RB <= src_hi) {
 #pragma unroll
-                for (int a = 0; a < TPW; ++a)
-                    if (a < nt) {
+                    for (int t = 0; t < NTP; ++t)
+                        if (t < n) {
+                            if constexpr (RPL == 4) {
+                                const f32x4 v = *reinterpret_cast<mg_gf32x4 *>(dp[t] + r0);
+                                xpf[t][0] = v.x, xpf[t][1] = v.y, xpf[t][2] = v.z, xpf[t][3] = v.w;
+                            } else if constexpr (RPL == 2) {
+                                const f32x2 v = *reinterpret_cast<mg_gf32x2 *>(dp[t] + r0);
+                                xpf[t][0] = v.x, xpf[t][1] = v.y;
+                            } else {
+                                xpf[t][0] = dp[t][r0];
+                            }
+                        }
+                } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) xpf[a][e] = in[e] ? dp[a][r0 + 64 * e] : 0.f;
-                    }
+                    for (int t = 0; t < NTP; ++t)
+                        if (t < n) {
+#pragma unroll
+                            for (int e = 0; e < RPL; ++e) xpf[t][e] = (r0 + e < src_hi) ? dp[t][r0 + e] : 0.f;
+                        }
+                }
             }
-            const int nr = (int)((cend - c0 < SVDQ_BLK_ROWS) ? (cend - c0) : SVDQ_BLK_ROWS);
-            if (gmean) {      // (add_mean only) compacted rows c0 + 64 e + lane: no global load is left in the compute phase
+            const int nr = (int)((cend - c0 < RB) ? (cend - c0) : RB);
+            if (gmean) {      // (add_mean only) compacted rows c0 + 64 e + lane
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mpf[e] = (64 * e + lane < nr) ? gmean[c0 + 64 * e + lane] : 0.f;
+                for (int e = 0; e < RPL; ++e) mpf[e] = (64 * e + lane < nr) ? gmean[c0 + 64 * e + lane] : 0.f;
             }
-            us = ustage_plan<ES>(c0, nr, k, nl);
+            const UStage us = ustage_plan<ES>(c0, nr, k, nl);
 #pragma unroll
             for (int s = 0; s < SV; ++s) {
-                const int v = tid + 64 * W * s;
+                const int v = lane + 64 * s;
                 if (v < us.nv) {
-                    const uint8_t *g = (v < us.nvh) ? gUh + us.a0h + 16ll * v : gUl + us.a0l + 16ll * (v - us.nvh);
-                    ureg[s] = *(mg_gf32x4 *)g;
+                    const uint8_t *gp = (v < us.nvh) ? gUh + us.a0h + 16ll * v : gUl + us.a0l + 16ll * (v - us.nvh);
+                    ureg[s] = *(mg_gf32x4 *)gp;
                 }
             }
         };
         prefetch(src, cpos);
-        int buf = 0;
         while (true) {
             // ---- selection of the block whose data sits in the registers
-            bool sel[4];
-            int rank[4], count;
+            int count;
+            int slot[RPL];      // WALK: where the lane's rows go in the strips
             if constexpr (WALK) {
                 int base = 0;
                 const int64_t room = cend - cpos;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < RPL; ++e) {
                     const bool s = inv ? (mkpf[e] == 0u) : (mkpf[e] != 0u && mkpf[e] != 0x100u);
                     const unsigned long long bal = __ballot(s);
-                    rank[e] = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    sel[e] = s && rank[e] < room;
+                    const int rank = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    // a selected row goes to its rank, any other to the lane's dump slot (no branch around the writes)
+                    slot[e] = (s && rank < room) ? rank : RB + 4 + lane;
                     base += (int)__popcll(bal);
                 }
                 count = base < room ? base : (int)room;
             } else {
-                count = (int)((src_hi - src < SVDQ_BLK_ROWS) ? (src_hi - src) : SVDQ_BLK_ROWS);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    rank[e] = 64 * e + lane;
-                    sel[e] = rank[e] < count;
-                }
+                count = (int)((src_hi - src < RB) ? (src_hi - src) : RB);
             }
-            // ---- registers -> LDS
-            uint8_t *Ucur = Ubuf + buf * ubytes;
-            const UStage cur = us;
+            // ---- registers -> LDS (the staging layout is a function of the block's first row: recomputed, not kept)
+            const UStage cur = ustage_plan<ES>(cpos, (int)((cend - cpos < RB) ? (cend - cpos) : RB), k, nl);
 #pragma unroll
             for (int s = 0; s < SV; ++s) {
-                const int v = tid + 64 * W * s;
-                if (v < cur.nv) reinterpret_cast<f32x4 *>(Ucur)[v] = ureg[s];
+                const int v = lane + 64 * s;
+                if (v < cur.nv) reinterpret_cast<f32x4 *>(Ubuf)[v] = ureg[s];
             }
             if (gmean) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Xw[TPW * DG_XS + 64 * e + lane] = mpf[e];
+                for (int e = 0; e < RPL; ++e) X[NTP * XSD + 64 * e + lane] = mpf[e];
             }
-            {
-                int slot[4];      // a selected row goes to its rank, any other to the lane's dump slot
 #pragma unroll
-                for (int e = 0; e < 4; ++e) slot[e] = sel[e] ? rank[e] : SVDQ_BLK_ROWS + lane;
+            for (int t = 0; t < NTP; ++t) {      // strips past the plan's tasks hold don't-cares (their C is zero)
+                if constexpr (WALK) {
 #pragma unroll
-                for (int a = 0; a < TPW; ++a)      // all eight strips (those past the wave's tasks hold don't-cares)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Xw[a * DG_XS + slot[e]] = xpf[a][e];
+                    for (int e = 0; e < RPL; ++e) X[t * XSD + slot[e]] = xpf[t][e];
+                } else if constexpr (RPL == 4) {
+                    f32x4 v = {xpf[t][0], xpf[t][1], xpf[t][2], xpf[t][3]};
+                    *reinterpret_cast<f32x4 *>(X + t * XSD + 4 * lane) = v;
+                } else if constexpr (RPL == 2) {
+                    f32x2 v = {xpf[t][0], xpf[t][1]};
+                    *reinterpret_cast<f32x2 *>(X + t * XSD + 2 * lane) = v;
+                } else {
+                    X[t * XSD + lane] = xpf[t][0];
+                }
             }
-            if constexpr (W > 1)
-                __syncthreads();
-            else
-                lds_fence();
+            lds_fence();
             // ---- the next block's loads
-            const int64_t nsrc = src + SVDQ_BLK_ROWS, ncpos = cpos + count;
+            const int64_t nsrc = src + RB, ncpos = cpos + count;
             const bool more = nsrc < src_hi && ncpos < cend;
             if (more) prefetch(nsrc, ncpos);
-            // ---- compute: rows 64 m + lane, two at a time
-            const T *Uh = reinterpret_cast<const T *>(Ucur) + cur.offh;
-            const T *Ul = reinterpret_cast<const T *>(Ucur + 16 * cur.nvh) + cur.offl;
-#pragma unroll 1
-            for (int h = 0; h < 2; ++h) {
-                if (128 * h >= count) break;
-                const int qa = 128 * h + lane, qb = qa + 64;
-                const bool va = qa < count, vb = qb < count;
-                const int ra = va ? qa : 0, rb = vb ? qb : 0;
-                float hi[2][TPW], lo[2][TPW];
+            // ---- compute
+            if (count > 0) {
+                // per step: LDS byte address of the lane's element in the first tile, advance per tile
+                int ua[KMAX], ust[KMAX];
+                {
+                    const int baseH = cur.offh * ES, baseL = 16 * cur.nvh + cur.offl * ES;
 #pragma unroll
-                for (int a = 0; a < TPW; ++a) hi[0][a] = hi[1][a] = lo[0][a] = lo[1][a] = 0.f;
-#pragma unroll 4
-                for (int c = 0; c < k; ++c) {
-                    const float ua = u_val(Uh, ra * k + c), ub = u_val(Uh, rb * k + c);
-#pragma unroll
-                    for (int g = 0; g < TPW; g += 4) {
-                        const f32x4 cq = *reinterpret_cast<const f32x4 *>(Cw + c * TPW + g);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            hi[0][g + a] = fmaf(ua, cq[a], hi[0][g + a]);
-                            hi[1][g + a] = fmaf(ub, cq[a], hi[1][g + a]);
-                        }
+                    for (int s = 0; s < KMAX; ++s) {
+                        int c = slot_col(s);
+                        if (c < 0) c = 0;                                   // an idle slot reads a staged value (times C = 0)
+                        const int row = col + ((PACK2 && s >= 2) ? 16 : 0);
+                        const bool hi = c < k;
+                        const int w = hi ? k : nl;
+                        ua[s] = (hi ? baseH : baseL) + (row * w + (hi ? c : c - k)) * ES;
+                        ust[s] = TROWS * w * ES;
                     }
                 }
-#pragma unroll 4
-                for (int jx = 0; jx < nl; ++jx) {
-                    const float ua = u_val(Ul, ra * nl + jx), ub = u_val(Ul, rb * nl + jx);
+                f32x2 se2[TT], sx2[TT], sr2[TT];
+                float sa0[TT], sa1[TT];
 #pragma unroll
-                    for (int g = 0; g < TPW; g += 4) {
-                        const f32x4 cq = *reinterpret_cast<const f32x4 *>(Cw + (k + jx) * TPW + g);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            lo[0][g + a] = fmaf(ua, cq[a], lo[0][g + a]);
-                            lo[1][g + a] = fmaf(ub, cq[a], lo[1][g + a]);
-                        }
-                    }
+                for (int tt = 0; tt < TT; ++tt) {
+                    se2[tt] = sx2[tt] = sr2[tt] = f32x2{0.f, 0.f};
+                    sa0[tt] = sa1[tt] = 0.f;
                 }
-                const float ma = gmean ? Xw[TPW * DG_XS + ra] : 0.f;
-                const float mb = gmean ? Xw[TPW * DG_XS + rb] : 0.f;
+                auto tile = [&](int ti, auto masked_c) {
+                    constexpr bool MASKED = decltype(masked_c)::value;
+                    float a[KMAX];
 #pragma unroll
-                for (int a = 0; a < TPW; ++a) {      // no branch on the wave's task count: strips past it are never stored
-                    {
-                        // the lane's two rows: products and their two-term sums in fp32 (each term is a rounded fp32
-                        // square -- what the reference's fp32 norms see), the running sums in fp64.  Rows past the
-                        // block's end contribute exact zeros: no divergent branch around the sums.
-                        const float xa = va ? Xw[a * DG_XS + ra] : 0.f, xb = vb ? Xw[a * DG_XS + rb] : 0.f;
-                        float ca = __fadd_rn(hi[0][a], lo[0][a]), cb = __fadd_rn(hi[1][a], lo[1][a]);
+                    for (int s = 0; s < KMAX; ++s)
+                        if (s < KT) {      // wave-uniform
+                            a[s] = lds_u(Ubuf, ua[s], T{});
+                            ua[s] += ust[s];
+                        }
+                    const int rb = ti * TROWS + (PACK2 ? 16 * (col >> 3) : 0) + 4 * g;      // the lane's four rows
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < KMAX; ++s)
+                            if (s < KT) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], creg[tt][s], acc, 0, 0, 0);
+                        f32x4 x = *reinterpret_cast<const f32x4 *>(X + task[tt] * XSD + rb);
                         if (gmean) {
-                            ca = __fadd_rn(ca, ma);
-                            cb = __fadd_rn(cb, mb);
+                            const f32x4 m = *reinterpret_cast<const f32x4 *>(X + NTP * XSD + rb);
+                            acc.x = __fadd_rn(acc.x, m.x), acc.y = __fadd_rn(acc.y, m.y);
+                            acc.z = __fadd_rn(acc.z, m.z), acc.w = __fadd_rn(acc.w, m.w);
                         }
-                        ca = va ? ca : 0.f;
-                        cb = vb ? cb : 0.f;
-                        const float ea = __fsub_rn(xa, ca), eb = __fsub_rn(xb, cb);
-                        se[a] += (double)fmaf(eb, eb, ea * ea);
-                        sx[a] += (double)fmaf(xb, xb, xa * xa);
-                        sr[a] += (double)fmaf(cb, cb, ca * ca);
-                        sa[a] += (double)(fabsf(ea) + fabsf(eb));
-                        mx[a] = fmaxf(mx[a], fmaxf(fabsf(ea), fabsf(eb)));      // a NaN error reaches max through se (k_diag_finish)
+                        if constexpr (MASKED) {      // rows past the block's count contribute exact zeros
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const bool ok = rb + v < count;
+                                x[v] = ok ? x[v] : 0.f;
+                                acc[v] = ok ? acc[v] : 0.f;
+                            }
+                        }
+                        const f32x2 m1 = {-1.f, -1.f};
+                        const f32x2 x01 = {x.x, x.y}, x23 = {x.z, x.w}, c01 = {acc.x, acc.y}, c23 = {acc.z, acc.w};
+                        const f32x2 e01 = __builtin_elementwise_fma(c01, m1, x01);      // x - rec, one rounding
+                        const f32x2 e23 = __builtin_elementwise_fma(c23, m1, x23);
+                        se2[tt] = __builtin_elementwise_fma(e01, e01, se2[tt]);
+                        se2[tt] = __builtin_elementwise_fma(e23, e23, se2[tt]);
+                        sx2[tt] = __builtin_elementwise_fma(x01, x01, sx2[tt]);
+                        sx2[tt] = __builtin_elementwise_fma(x23, x23, sx2[tt]);
+                        sr2[tt] = __builtin_elementwise_fma(c01, c01, sr2[tt]);
+                        sr2[tt] = __builtin_elementwise_fma(c23, c23, sr2[tt]);
+                        sa0[tt] += fabsf(e01.x) + fabsf(e01.y);
+                        sa1[tt] += fabsf(e23.x) + fabsf(e23.y);
+                        // a NaN error reaches max through se (k_diag_finish)
+                        mx[tt] = fmaxf(mx[tt], fmaxf(fmaxf(fabsf(e01.x), fabsf(e01.y)), fmaxf(fabsf(e23.x), fabsf(e23.y))));
                     }
+                };
+                const int nfull = count / TROWS;
+#pragma unroll 2
+                for (int ti = 0; ti < nfull; ++ti) tile(ti, DiagBool<false>{});
+                if (nfull * TROWS < count) tile(nfull, DiagBool<true>{});
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    se[tt] += (double)(se2[tt].x + se2[tt].y);
+                    sx[tt] += (double)(sx2[tt].x + sx2[tt].y);
+                    sr[tt] += (double)(sr2[tt].x + sr2[tt].y);
+                    sa[tt] += (double)(sa0[tt] + sa1[tt]);
                 }
             }
             if (!more) break;
             src = nsrc;
             cpos = ncpos;
-            buf ^= 1;
-            lds_fence();      // this wave's X strip is rewritten next
+            lds_fence();      // the strips and the basis rows are rewritten next
         }
     }
-    // wave reduction in a fixed order (xor butterflies), lane 0 writes the unit's partials of the wave's tasks
+    // the lanes that hold one task's columns meet in a fixed order (xor butterflies); one lane writes the unit's partial
 #pragma unroll
-    for (int a = 0; a < TPW; ++a) {
-        double qa = se[a], qb = sx[a], qc = sr[a], qd = sa[a];
-        float q = mx[a];
+    for (int tt = 0; tt < TT; ++tt) {
+        double qa = se[tt], qb = sx[tt], qc = sr[tt], qd = sa[tt];
+        float q = mx[tt];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int off = 32; off >= (PACK2 ? 8 : 16); off >>= 1) {
             qa += __shfl_xor(qa, off);
             qb += __shfl_xor(qb, off);
             qc += __shfl_xor(qc, off);
@@ -709,8 +806,8 @@ __global__ __launch_bounds__(64 * W, (TPW == 4 ? 4 : 2)) void k_diag(const SvdqP
             const float o = __shfl_xor(q, off);
             q = (q != q) ? q : ((o != o) ? o : (o > q ? o : q));
         }
-        if (lane == 0 && a < nt) {
-            DiagPart &dst = part[(size_t)blockIdx.x * n + t0 + a];
+        if (lane < (PACK2 ? 8 : 16) && task[tt] < n) {
+            DiagPart &dst = part[(size_t)blockIdx.x * n + task[tt]];
             dst.se = qa;
             dst.sx = qb;
             dst.sr = qc;
@@ -905,23 +1002,22 @@ __global__ void k_one_hot(int n, float *w) {
     if (e < n * n) w[e] = (e / n == e % n) ? 1.f : -1.f;
 }
 
-template <int W, int TPW>
+#ifndef SVDQ_DIAG_RPL_MID
+#define SVDQ_DIAG_RPL_MID 2      // rows per lane and block of the 9..24-task variants (A/B builds)
+#endif
+template <int NTP, int RPL, bool PACK2, bool FULL>
 static void launch_diag(const svdq_plan *pl, const void *ptrs, const void *mask_ptrs, const int64_t *unit_start,
                         const int64_t *rows_dev, const int32_t *kk, const int32_t *rr, const uint8_t *basis,
                         const float *mean, int add_mean, const float *ctask, DiagPart *part, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
     auto mp = reinterpret_cast<const uint8_t *const *>(mask_ptrs);
+    using G = DiagGeom<NTP, RPL, PACK2>;
     const int n = pl->n_tasks, es = pl->cfg.fp16 ? 2 : 4;
-    const size_t lds = 2 * (size_t)svdq_align_up((int64_t)SVDQ_BLK_ROWS * n * es + 64, 16) +
-                       (size_t)W * n * TPW * 4 + (size_t)W * (TPW + 1) * DG_XS * 4;
+    const size_t lds = (size_t)svdq_align_up((int64_t)G::RB * n * es + 48, 16) +
+                       (size_t)(NTP + 1) * diag_xs(G::RB, mp != nullptr) * 4;
 #define SVDQ_DIAG_LAUNCH(F16, WALK_)                                                                                   \
-    do {                                                                                                               \
-        if (lds > 65536)                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<W, TPW, F16, WALK_>),                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-        hipLaunchKernelGGL((k_diag<W, TPW, F16, WALK_>), dim3(pl->n_units), dim3(64 * W), lds, st, pl->d_params,        \
-                           pl->d_units, pp, mp, unit_start, rows_dev, n, kk, rr, basis, mean, add_mean, ctask, part);  \
-    } while (0)
+    hipLaunchKernelGGL((k_diag<NTP, RPL, PACK2, FULL, F16, WALK_>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params, \
+                       pl->d_units, pp, mp, unit_start, rows_dev, n, kk, rr, basis, mean, add_mean, ctask, part)
     if (pl->cfg.fp16) {
         if (mp) SVDQ_DIAG_LAUNCH(true, true); else SVDQ_DIAG_LAUNCH(true, false);
     } else {
@@ -951,18 +1047,25 @@ static int run_diagnostics(const char *who, const svdq_plan *pl, const void *del
     const uint8_t *sm = reinterpret_cast<const uint8_t *>(small);
     auto kk = reinterpret_cast<const int32_t *>(sm + L.k_off), rr = reinterpret_cast<const int32_t *>(sm + L.r_off);
     auto bs = reinterpret_cast<const uint8_t *>(basis);
-    // eight tasks per wavefront.  (Four -- twice the wavefronts, 128 registers, four waves per SIMD -- measured 1.5x
-    // SLOWER: 5.21 against 3.43 ms at ViT-L-14 x 8; the kernel is bound by instruction issue, and the second wave's
-    // own copy of the row reads, conversions and barriers costs more than the extra resident waves hide.)
-#define SVDQ_DIAG_CASE(W_) \
-    case W_: launch_diag<W_, 8>(pl, delta_ptrs, mask_ptrs, unit_start, rows_dev, kk, rr, bs, mean, add_mean, ctask, part, st); break
-    switch ((int)((n + 7) / 8)) {
-        SVDQ_DIAG_CASE(1); SVDQ_DIAG_CASE(2); SVDQ_DIAG_CASE(3); SVDQ_DIAG_CASE(4);
-        default:
-            svdq_set_error("%s: unsupported task count %d", who, (int)n);
-            return SVDQ_EUNSUPPORTED;
+    // variants by padded task count (the prefetch registers and the X strips are sized by it), each also for plans with
+    // exactly that many tasks
+#define SVDQ_DIAG_ARGS pl, delta_ptrs, mask_ptrs, unit_start, rows_dev, kk, rr, bs, mean, add_mean, ctask, part, st
+#define SVDQ_DIAG_PICK(NTP_, RPL_, PACK_)                                                                              \
+    do {                                                                                                               \
+        if (n == NTP_) launch_diag<NTP_, RPL_, PACK_, true>(SVDQ_DIAG_ARGS);                                            \
+        else launch_diag<NTP_, RPL_, PACK_, false>(SVDQ_DIAG_ARGS);                                                     \
+    } while (0)
+    if (n <= 8) SVDQ_DIAG_PICK(8, 4, true);
+    else if (n <= 16) SVDQ_DIAG_PICK(16, SVDQ_DIAG_RPL_MID, false);
+    else if (n <= 20) SVDQ_DIAG_PICK(20, SVDQ_DIAG_RPL_MID, false);
+    else if (n <= 24) SVDQ_DIAG_PICK(24, SVDQ_DIAG_RPL_MID, false);
+    else if (n <= 32) SVDQ_DIAG_PICK(32, 1, false);
+    else {
+        svdq_set_error("%s: unsupported task count %d", who, (int)n);
+        return SVDQ_EUNSUPPORTED;
     }
-#undef SVDQ_DIAG_CASE
+#undef SVDQ_DIAG_PICK
+#undef SVDQ_DIAG_ARGS
     hipLaunchKernelGGL(k_diag_finish, dim3(pl->n_params, (int)n), dim3(64), 0, st, pl->d_params, rows_dev, (int)n, part, out);
     return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
 }
