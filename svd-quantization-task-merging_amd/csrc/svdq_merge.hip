@@ -728,38 +728,50 @@ __global__ __launch_bounds__(64) void k_diag(const SvdqParam *__restrict__ param
                     se2[tt] = sx2[tt] = sr2[tt] = f32x2{0.f, 0.f};
                     sa0[tt] = sa1[tt] = 0.f;
                 }
-                auto tile = [&](int ti, auto masked_c) {
-                    constexpr bool MASKED = decltype(masked_c)::value;
-                    float a[KMAX];
+                // the A operands of one tile: all KMAX steps, no branch -- a step past the parameter's columns reads a staged
+                // value against C = 0 (at most one such step unless the plan has fewer tasks than the variant is padded to)
+                auto load_a = [&](float (&a)[KMAX]) {
 #pragma unroll
-                    for (int s = 0; s < KMAX; ++s)
-                        if (s < KT) {      // wave-uniform
-                            a[s] = lds_u(Ubuf, ua[s], T{});
-                            ua[s] += ust[s];
-                        }
+                    for (int s = 0; s < KMAX; ++s) {
+                        a[s] = lds_u(Ubuf, ua[s], T{});
+                        ua[s] += ust[s];
+                    }
+                };
+                auto tile = [&](int ti, const float (&a)[KMAX], auto masked_c) {
+                    constexpr bool MASKED = decltype(masked_c)::value;
                     const int rb = ti * TROWS + (PACK2 ? 16 * (col >> 3) : 0) + 4 * g;      // the lane's four rows
+                    f32x4 x[TT], acc[TT];
 #pragma unroll
                     for (int tt = 0; tt < TT; ++tt) {
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        x[tt] = *reinterpret_cast<const f32x4 *>(X + task[tt] * XSD + rb);
+                        acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
 #pragma unroll
-                        for (int s = 0; s < KMAX; ++s)
-                            if (s < KT) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], creg[tt][s], acc, 0, 0, 0);
-                        f32x4 x = *reinterpret_cast<const f32x4 *>(X + task[tt] * XSD + rb);
-                        if (gmean) {
-                            const f32x4 m = *reinterpret_cast<const f32x4 *>(X + NTP * XSD + rb);
-                            acc.x = __fadd_rn(acc.x, m.x), acc.y = __fadd_rn(acc.y, m.y);
-                            acc.z = __fadd_rn(acc.z, m.z), acc.w = __fadd_rn(acc.w, m.w);
+                    for (int s = 0; s < KMAX; ++s)      // the task tiles' chains are independent: interleaved
+#pragma unroll
+                        for (int tt = 0; tt < TT; ++tt)
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], creg[tt][s], acc[tt], 0, 0, 0);
+                    if (gmean) {
+                        const f32x4 m = *reinterpret_cast<const f32x4 *>(X + NTP * XSD + rb);
+#pragma unroll
+                        for (int tt = 0; tt < TT; ++tt) {
+                            acc[tt].x = __fadd_rn(acc[tt].x, m.x), acc[tt].y = __fadd_rn(acc[tt].y, m.y);
+                            acc[tt].z = __fadd_rn(acc[tt].z, m.z), acc[tt].w = __fadd_rn(acc[tt].w, m.w);
                         }
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) {
                         if constexpr (MASKED) {      // rows past the block's count contribute exact zeros
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 const bool ok = rb + v < count;
-                                x[v] = ok ? x[v] : 0.f;
-                                acc[v] = ok ? acc[v] : 0.f;
+                                x[tt][v] = ok ? x[tt][v] : 0.f;
+                                acc[tt][v] = ok ? acc[tt][v] : 0.f;
                             }
                         }
                         const f32x2 m1 = {-1.f, -1.f};
-                        const f32x2 x01 = {x.x, x.y}, x23 = {x.z, x.w}, c01 = {acc.x, acc.y}, c23 = {acc.z, acc.w};
+                        const f32x2 x01 = {x[tt].x, x[tt].y}, x23 = {x[tt].z, x[tt].w};
+                        const f32x2 c01 = {acc[tt].x, acc[tt].y}, c23 = {acc[tt].z, acc[tt].w};
                         const f32x2 e01 = __builtin_elementwise_fma(c01, m1, x01);      // x - rec, one rounding
                         const f32x2 e23 = __builtin_elementwise_fma(c23, m1, x23);
                         se2[tt] = __builtin_elementwise_fma(e01, e01, se2[tt]);
@@ -774,10 +786,18 @@ __global__ __launch_bounds__(64) void k_diag(const SvdqParam *__restrict__ param
                         mx[tt] = fmaxf(mx[tt], fmaxf(fmaxf(fabsf(e01.x), fabsf(e01.y)), fmaxf(fabsf(e23.x), fabsf(e23.y))));
                     }
                 };
+                // the next tile's operands are read before this tile's chain is issued (the read one past the last tile
+                // stays inside the workgroup's LDS: the strips follow the basis rows)
                 const int nfull = count / TROWS;
-#pragma unroll 2
-                for (int ti = 0; ti < nfull; ++ti) tile(ti, DiagBool<false>{});
-                if (nfull * TROWS < count) tile(nfull, DiagBool<true>{});
+                float a0[KMAX], a1[KMAX];
+                load_a(a0);
+                for (int ti = 0; ti < nfull; ++ti) {
+                    load_a(a1);
+                    tile(ti, a0, DiagBool<false>{});
+#pragma unroll
+                    for (int s = 0; s < KMAX; ++s) a0[s] = a1[s];
+                }
+                if (nfull * TROWS < count) tile(nfull, a0, DiagBool<true>{});
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt) {
                     se[tt] += (double)(se2[tt].x + se2[tt].y);
@@ -1056,9 +1076,11 @@ static int run_diagnostics(const char *who, const svdq_plan *pl, const void *del
         else launch_diag<NTP_, RPL_, PACK_, false>(SVDQ_DIAG_ARGS);                                                     \
     } while (0)
     if (n <= 8) SVDQ_DIAG_PICK(8, 4, true);
+    else if (n <= 12) SVDQ_DIAG_PICK(12, SVDQ_DIAG_RPL_MID, false);
     else if (n <= 16) SVDQ_DIAG_PICK(16, SVDQ_DIAG_RPL_MID, false);
     else if (n <= 20) SVDQ_DIAG_PICK(20, SVDQ_DIAG_RPL_MID, false);
     else if (n <= 24) SVDQ_DIAG_PICK(24, SVDQ_DIAG_RPL_MID, false);
+    else if (n <= 28) SVDQ_DIAG_PICK(28, 1, false);
     else if (n <= 32) SVDQ_DIAG_PICK(32, 1, false);
     else {
         svdq_set_error("%s: unsupported task count %d", who, (int)n);
