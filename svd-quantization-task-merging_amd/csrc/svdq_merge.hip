@@ -84,28 +84,41 @@ template <> struct UElem<false> { using type = float; };
 __device__ __forceinline__ float u_val(const __half *u, int i) { return __half2float(u[i]); }
 __device__ __forceinline__ float u_val(const float *u, int i) { return u[i]; }
 
-// global -> LDS, 16 B per lane, whole tile contiguous (the mirror image of pass 2's copy_out)
-__device__ __forceinline__ void copy_in(void *lds_dst, const uint8_t *gsrc, int nbytes, int lane) {
-    const int nvec = nbytes >> 4;
-    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(gsrc);
-    f32x4 *d4 = reinterpret_cast<f32x4 *>(lds_dst);
-    for (int i = lane; i < nvec; i += 64) d4[i] = s4[i];
-    uint8_t *db = reinterpret_cast<uint8_t *>(lds_dst);
-    for (int b = (nvec << 4) + 2 * lane; b < nbytes; b += 128)
-        *reinterpret_cast<uint16_t *>(db + b) = *reinterpret_cast<const uint16_t *>(gsrc + b);
-}
-
 __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One wavefront per work unit of the plan; 256-row blocks; lane l owns rows l, 64 + l, 128 + l, 192 + l of a block (the
-// [256, k] / [256, nl] tiles arrive in LDS with 16-byte loads; a lane's row reads are then conflict-free).  Columns
-// outermost: one coefficient read serves the lane's four rows, and the four fma chains are independent.
-// NS = compiled-in number of sets (1, 2, 4, 8 >= n_sets).
-template <bool U16, int NS>
+// where a block's staged basis rows sit (wave-uniform): the two parts are fetched with aligned 16-byte loads and kept
+// row-major, one after the other, in LDS
+struct UStage {
+    int nvh, nv;     // 16-byte vectors of the U_high part, of both parts
+    int offh, offl;  // element offset of the block's first row inside each part
+    int64_t a0h, a0l;
+};
+template <int ES>
+__device__ __forceinline__ UStage ustage_plan(int64_t c0, int nr, int k, int nl) {
+    UStage u;
+    const int64_t b0h = c0 * k * ES, b1h = (c0 + nr) * (int64_t)k * ES;
+    const int64_t b0l = c0 * nl * ES, b1l = (c0 + nr) * (int64_t)nl * ES;
+    u.a0h = b0h & ~15ll;
+    u.a0l = b0l & ~15ll;
+    u.nvh = k > 0 ? (int)((b1h - u.a0h + 15) >> 4) : 0;
+    u.nv = u.nvh + (nl > 0 ? (int)((b1l - u.a0l + 15) >> 4) : 0);
+    u.offh = (int)(b0h - u.a0h) / ES;
+    u.offl = (int)(b0l - u.a0l) / ES;
+    return u;
+}
+
+// One wavefront per work unit of the plan.  Blocks of RB = 64 RPL rows (256 for N <= 8, 128 for N <= 16, 64 above: the
+// block's basis rows then fit the same few registers per lane); lane l owns rows l, 64 + l, ... of a block (conflict-free
+// row reads from the row-major LDS image).  Software pipeline, one block deep: while block b is computed from LDS, the
+// loads of block b + 1 -- its run of basis rows (16-byte loads), its mean and base rows -- are in flight into registers
+// (round 3 loaded a tile, fenced, computed, fenced: nothing was in flight during the compute phase and the counters showed
+// 84 % of the wave cycles waiting).  Columns outermost: one coefficient read serves the lane's rows, the fma chains are
+// independent.  NS = compiled-in number of sets (1, 2, 4, 8 >= n_sets).
+template <bool U16, int NS, int RPL>
 __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__restrict__ params,
                                                           const SvdqUnit *__restrict__ units,
                                                           const int64_t *__restrict__ rows_dev, int NT, int n_sets,
@@ -120,12 +133,15 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
                                                           float *const *__restrict__ out_ptrs) {
     using T = typename UElem<U16>::type;
     constexpr int ES = U16 ? 2 : 4;
-    // dynamic LDS: [256 x N] basis elements (the U_high tile, then the U_low tile), then the coefficient sets
+    constexpr int RB = 64 * RPL;
+    constexpr int NMAX = RPL == 4 ? 8 : (RPL == 2 ? 16 : 32);       // tasks this block size is launched for
+    constexpr int SV = (RB * NMAX * ES / 16 + 2 + 63) / 64;          // 16-byte vectors of one block's basis rows per lane
+    // dynamic LDS: the staged basis rows (both parts + alignment slack), then the coefficient sets
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    T *UT = reinterpret_cast<T *>(lds_raw);
-    float *C = reinterpret_cast<float *>(lds_raw + (size_t)SVDQ_BLK_ROWS * NT * ES);   // [column][NS]
-    float *SH = C + NS * NT;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, n = NT;
+    const int ubytes = (int)svdq_align_up((int64_t)RB * n * ES + 48, 16);
+    float *C = reinterpret_cast<float *>(lds_raw + ubytes);   // [column][NS]
+    float *SH = C + NS * n;
     const SvdqUnit ud = units[blockIdx.x];
     const int p = ud.param;
     const int64_t D = rows_dev ? rows_dev[p] : params[p].rows;
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
     int64_t r_end = r_begin + ud.nrows;
     if (r_end > D) r_end = D;
     if (r_begin >= r_end) return;
-    const int k = k_in[p], r = r_in[p], nl = r - k, n = NT;
+    const int k = k_in[p], r = r_in[p], nl = r - k;
     for (int e = lane; e < NS * n; e += 64) {      // transposed: the NS coefficients of a column side by side
         const int i = e / NS, s = e % NS;
         C[e] = s < n_sets ? cbar[((size_t)p * n_sets + s) * n + i] : 0.f;
@@ -147,25 +163,57 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
     mg_gfloat *gmean = meanbuf ? (mg_gfloat *)(meanbuf + params[p].mean_off) : nullptr;
     mg_gfloat *gbase = base_ptrs ? (mg_gfloat *)base_ptrs[p] : nullptr;
     mg_gfloat_w *gout = (mg_gfloat_w *)out_ptrs[p];
-    T *Uh = UT, *Ul = UT + SVDQ_BLK_ROWS * k;
 
-    for (int64_t rb = r_begin; rb < r_end; rb += SVDQ_BLK_ROWS) {
-        const int rows_blk = (int)((D - rb < SVDQ_BLK_ROWS) ? (D - rb) : SVDQ_BLK_ROWS);
-        if (k > 0) copy_in(Uh, gUh + rb * (int64_t)k * ES, rows_blk * k * ES, lane);
-        if (nl > 0) copy_in(Ul, gUl + rb * (int64_t)nl * ES, rows_blk * nl * ES, lane);
-        float mv[4], bv[4];
-        int rl[4];      // the lane's rows, clamped into the block (results of clamped rows are not stored)
+    // ---- the loads of one block into registers
+    f32x4 ureg[SV];
+    float mpf[RPL] = {}, bpf[RPL] = {};
+    auto prefetch = [&](int64_t rb) {
+        const int nr = (int)((r_end - rb < RB) ? (r_end - rb) : RB);
+        const UStage us = ustage_plan<ES>(rb, nr, k, nl);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int s = 0; s < SV; ++s) {
+            const int v = lane + 64 * s;
+            if (v < us.nv) {
+                const uint8_t *gp = (v < us.nvh) ? gUh + us.a0h + 16ll * v : gUl + us.a0l + 16ll * (v - us.nvh);
+                ureg[s] = *(mg_gf32x4 *)gp;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) {      // rows past the block's end are clamped into it (their results are not stored)
+            const int q = 64 * m + lane;
+            const int64_t row = rb + (q < nr ? q : nr - 1);
+            if (gmean) mpf[m] = gmean[row];
+            if (gbase) bpf[m] = gbase[row];
+        }
+    };
+    prefetch(r_begin);
+    for (int64_t rb = r_begin; rb < r_end; rb += RB) {
+        const int rows_blk = (int)((r_end - rb < RB) ? (r_end - rb) : RB);
+        // ---- registers -> LDS
+        const UStage cur = ustage_plan<ES>(rb, rows_blk, k, nl);
+#pragma unroll
+        for (int s = 0; s < SV; ++s) {
+            const int v = lane + 64 * s;
+            if (v < cur.nv) reinterpret_cast<f32x4 *>(lds_raw)[v] = ureg[s];
+        }
+        float mv[RPL], bv[RPL];
+        int rl[RPL];      // the lane's rows, clamped into the block
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) {
             const int q = 64 * m + lane;
             rl[m] = q < rows_blk ? q : rows_blk - 1;
-            mv[m] = gmean ? gmean[rb + rl[m]] : 0.f;
-            bv[m] = gbase ? gbase[rb + rl[m]] : 0.f;
+            mv[m] = mpf[m];
+            bv[m] = bpf[m];
         }
         lds_fence();
-        float hi[4][NS], lo[4][NS];
+        // ---- the next block's loads
+        if (rb + RB < r_end) prefetch(rb + RB);
+        // ---- compute
+        const T *Uh = reinterpret_cast<const T *>(lds_raw) + cur.offh;
+        const T *Ul = reinterpret_cast<const T *>(lds_raw + 16 * cur.nvh) + cur.offl;
+        float hi[RPL][NS], lo[RPL][NS];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < RPL; ++m)
 #pragma unroll
             for (int s = 0; s < NS; ++s) hi[m][s] = lo[m][s] = 0.f;
         for (int i = 0; i < k; ++i) {
@@ -173,7 +221,7 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
 #pragma unroll
             for (int s = 0; s < NS; ++s) c[s] = C[i * NS + s];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < RPL; ++m) {
                 const float u = u_val(Uh, rl[m] * k + i);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) hi[m][s] = fmaf(u, c[s], hi[m][s]);
@@ -184,14 +232,14 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
 #pragma unroll
             for (int s = 0; s < NS; ++s) c[s] = C[(k + j) * NS + s];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < RPL; ++m) {
                 const float u = u_val(Ul, rl[m] * nl + j);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) lo[m][s] = fmaf(u, c[s], lo[m][s]);
             }
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < RPL; ++m) {
             float res = 0.f;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -207,7 +255,7 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
             if (gbase) res = __fadd_rn(bv[m], res);      // base + delta (merge.py:429-552)
             if (64 * m + lane < rows_blk) gout[rb + 64 * m + lane] = res;
         }
-        lds_fence();
+        lds_fence();      // the basis rows are rewritten next
     }
 }
 
@@ -236,54 +284,12 @@ __device__ __forceinline__ SrcRange unit_source_range(const SvdqParam &pd, int u
     return s;
 }
 
-// rows [c0, c0 + n) of a row-major [rows, w] basis part -> LDS with aligned 16-byte loads (the part starts 256-aligned
-// and is padded to 256 bytes, so rounding both ends to 16 stays inside it); returns the element offset of row c0
-template <int ES>
-__device__ __forceinline__ int stage_rows(uint8_t *lds, const uint8_t *g, int64_t c0, int n, int w, int lane) {
-    const int64_t b0 = c0 * w * ES, b1 = (c0 + n) * (int64_t)w * ES;
-    const int64_t a0 = b0 & ~15ll;
-    const int nvec = (int)((b1 - a0 + 15) >> 4);
-    mg_gf32x4 *s4 = (mg_gf32x4 *)(g + a0);
-    f32x4 *d4 = reinterpret_cast<f32x4 *>(lds);
-    for (int i = lane; i < nvec; i += 64) d4[i] = s4[i];
-    return (int)(b0 - a0) / ES;
-}
-
-// the chunk's selection: rank of each of the lane's four rows among the chunk's selected rows, and their number
-struct ChunkSel {
-    bool in[4], sel[4];
-    int rank[4];
-    int count;
-};
-// the chunk's mask bytes (0x100 = past the end of the range: selected by neither polarity), loaded one chunk ahead
-__device__ __forceinline__ void chunk_mask_load(unsigned (&mk)[4], mg_gbyte *__restrict__ gmask, int64_t src, int64_t hi,
-                                                int lane) {
-    const int64_t r = src + lane;
-    if (src + SVDQ_BLK_ROWS <= hi) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mk[e] = (unsigned)gmask[r + 64 * e];
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mk[e] = (r + 64 * e < hi) ? (unsigned)gmask[r + 64 * e] : 0x100u;
-    }
-}
-__device__ __forceinline__ ChunkSel chunk_select(const unsigned (&mk)[4], int inv, int64_t room) {
-    ChunkSel c;
-    int base = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        c.in[e] = mk[e] != 0x100u;
-        const bool s = inv ? (mk[e] == 0u) : (mk[e] != 0u && mk[e] != 0x100u);
-        const unsigned long long bal = __ballot(s);
-        c.rank[e] = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-        c.sel[e] = s && c.rank[e] < room;      // never past the unit's compacted rows, whatever the mask says
-        base += (int)__popcll(bal);
-    }
-    c.count = base < room ? base : (int)room;
-    return c;
-}
-
-template <bool U16, int NS>
+// One wavefront per work unit; chunk = RB = 64 RPL SOURCE rows (256 for N <= 8, 128 for N <= 16, 64 above), lane l owns rows
+// src + 64 e + l.  The same one-block software pipeline as k_merge_reconstruct: while chunk c is computed from LDS, chunk
+// c + 1's mask bytes and base rows and -- from the compacted position where chunk c ends, known once c's mask has been
+// counted -- the next RB basis rows and mean values (clamped to the unit; how many of them chunk c + 1 selects is not
+// known before its mask is, so a full block is fetched) are in flight into registers.
+template <bool U16, int NS, int RPL>
 __global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict__ params,
                                                      const SvdqUnit *__restrict__ units,
                                                      const int64_t *__restrict__ rows_dev, int NT, int n_sets,
@@ -300,11 +306,16 @@ __global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict
                                                      float *const *__restrict__ out_ptrs) {
     using T = typename UElem<U16>::type;
     constexpr int ES = U16 ? 2 : 4;
-    // dynamic LDS: the two staged runs of basis rows (each up to 256 rows + 16 bytes of alignment slack), the coefficients
+    constexpr int RB = 64 * RPL;
+    constexpr int NMAX = RPL == 4 ? 8 : (RPL == 2 ? 16 : 32);
+    constexpr int SV = (RB * NMAX * ES / 16 + 2 + 63) / 64;
+    // dynamic LDS: the staged basis rows, the staged mean values, the coefficient sets
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    float *C = reinterpret_cast<float *>(lds_raw + (size_t)SVDQ_BLK_ROWS * NT * ES + 64);   // [column][NS]
-    float *SH = C + NS * NT;
-    const int lane = threadIdx.x, u = blockIdx.x;
+    const int lane = threadIdx.x, u = blockIdx.x, n = NT;
+    const int ubytes = (int)svdq_align_up((int64_t)RB * n * ES + 48, 16);
+    float *M = reinterpret_cast<float *>(lds_raw + ubytes);      // [RB]
+    float *C = M + RB;                                           // [column][NS]
+    float *SH = C + NS * n;
     const SvdqUnit ud = units[u];
     const int p = ud.param;
     mg_gfloat_w *gout = (mg_gfloat_w *)out_ptrs[p];
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict
     int64_t cend = ud.row0 + ud.nrows;
     if (cend > D) cend = D;
     if (cpos > cend) cpos = cend;
-    const int k = k_in[p], r = r_in[p], nl = r - k, n = NT;
+    const int k = k_in[p], r = r_in[p], nl = r - k;
     for (int e = lane; e < NS * n; e += 64) {
         const int i = e / NS, s = e % NS;
         C[e] = s < n_sets ? cbar[((size_t)p * n_sets + s) * n + i] : 0.f;
@@ -332,45 +343,95 @@ __global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict
     mg_gfloat *gmean = meanbuf ? (mg_gfloat *)(meanbuf + pd.mean_off) : nullptr;
     mg_gfloat *gbase = base_ptrs ? (mg_gfloat *)base_ptrs[p] : nullptr;
     mg_gbyte *gmask = (mg_gbyte *)mask_ptrs[p];
-    uint8_t *ldsUh = lds_raw;
-    uint8_t *ldsUl = lds_raw + svdq_align_up((int64_t)SVDQ_BLK_ROWS * k * ES + 16, 16);
 
-    // the mask bytes and the base rows of a chunk do not depend on the selection: they are loaded one chunk ahead
-    unsigned mk[4];
-    float bnext[4];
-    auto ahead = [&](int64_t s0) {
-        chunk_mask_load(mk, gmask, s0, sr.hi, lane);
-        if (gbase) {
+    // ---- the loads of one chunk into registers
+    unsigned mk[RPL];      // mask bytes; 0x100 = past the end of the range: selected by neither polarity
+    float bpf[RPL] = {}, mpf[RPL] = {};
+    f32x4 ureg[SV];
+    auto prefetch = [&](int64_t s0, int64_t c0) {
+        const int64_t r0 = s0 + lane;
+        if (s0 + RB <= sr.hi) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) bnext[m] = (s0 + 64 * m + lane < sr.hi) ? gbase[s0 + 64 * m + lane] : 0.f;
+            for (int e = 0; e < RPL; ++e) {
+                mk[e] = (unsigned)gmask[r0 + 64 * e];
+                if (gbase) bpf[e] = gbase[r0 + 64 * e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) {
+                const bool in = r0 + 64 * e < sr.hi;
+                mk[e] = in ? (unsigned)gmask[r0 + 64 * e] : 0x100u;
+                if (gbase) bpf[e] = in ? gbase[r0 + 64 * e] : 0.f;
+            }
+        }
+        const int nr = (int)((cend - c0 < RB) ? (cend - c0) : RB);
+        if (gmean) {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) mpf[e] = (64 * e + lane < nr) ? gmean[c0 + 64 * e + lane] : 0.f;
+        }
+        const UStage us = ustage_plan<ES>(c0, nr, k, nl);
+#pragma unroll
+        for (int s = 0; s < SV; ++s) {
+            const int v = lane + 64 * s;
+            if (v < us.nv) {
+                const uint8_t *gp = (v < us.nvh) ? gUh + us.a0h + 16ll * v : gUl + us.a0l + 16ll * (v - us.nvh);
+                ureg[s] = *(mg_gf32x4 *)gp;
+            }
         }
     };
-    ahead(sr.lo);
-    for (int64_t src = sr.lo; src < sr.hi; src += SVDQ_BLK_ROWS) {
-        const ChunkSel cs = chunk_select(mk, sr.inv, cend - cpos);
-        int offh = 0, offl = 0;
-        if (cs.count > 0) {
-            if (k > 0) offh = stage_rows<ES>(ldsUh, gUh, cpos, cs.count, k, lane);
-            if (nl > 0) offl = stage_rows<ES>(ldsUl, gUl, cpos, cs.count, nl, lane);
-        }
-        float mv[4], bv[4];
+    prefetch(sr.lo, cpos);
+    for (int64_t src = sr.lo; src < sr.hi; src += RB) {
+        // ---- the chunk's selection: rank of each of the lane's rows among the chunk's selected rows, and their number
+        bool in[RPL], sel[RPL];
+        int rank[RPL], count;
+        {
+            int base = 0;
+            const int64_t room = cend - cpos;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            mv[m] = (gmean && cs.sel[m]) ? gmean[cpos + cs.rank[m]] : 0.f;
-            bv[m] = gbase ? bnext[m] : 0.f;
+            for (int e = 0; e < RPL; ++e) {
+                in[e] = mk[e] != 0x100u;
+                const bool sb = sr.inv ? (mk[e] == 0u) : (mk[e] != 0u && mk[e] != 0x100u);
+                const unsigned long long bal = __ballot(sb);
+                rank[e] = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                sel[e] = sb && rank[e] < room;      // never past the unit's compacted rows, whatever the mask says
+                base += (int)__popcll(bal);
+            }
+            count = base < room ? base : (int)room;
         }
-        if (src + SVDQ_BLK_ROWS < sr.hi) ahead(src + SVDQ_BLK_ROWS);
+        // ---- registers -> LDS
+        const UStage cur = ustage_plan<ES>(cpos, (int)((cend - cpos < RB) ? (cend - cpos) : RB), k, nl);
+#pragma unroll
+        for (int s = 0; s < SV; ++s) {
+            const int v = lane + 64 * s;
+            if (v < cur.nv) reinterpret_cast<f32x4 *>(lds_raw)[v] = ureg[s];
+        }
+        if (gmean) {
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) M[64 * e + lane] = mpf[e];
+        }
+        float bv[RPL];
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) bv[m] = bpf[m];
         lds_fence();
-        float res[4] = {0.f, 0.f, 0.f, 0.f};
-        if (cs.count > 0) {
-            const T *Uh = reinterpret_cast<const T *>(ldsUh) + offh;
-            const T *Ul = reinterpret_cast<const T *>(ldsUl) + offl;
-            int rl[4];
+        // ---- the next chunk's loads
+        if (src + RB < sr.hi) prefetch(src + RB, cpos + count);
+        // ---- compute
+        float res[RPL];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) rl[m] = cs.sel[m] ? cs.rank[m] : 0;
-            float hi[4][NS], lo[4][NS];
+        for (int m = 0; m < RPL; ++m) res[m] = 0.f;
+        if (count > 0) {
+            const T *Uh = reinterpret_cast<const T *>(lds_raw) + cur.offh;
+            const T *Ul = reinterpret_cast<const T *>(lds_raw + 16 * cur.nvh) + cur.offl;
+            int rl[RPL];
+            float mv[RPL];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < RPL; ++m) {
+                rl[m] = sel[m] ? rank[m] : 0;
+                mv[m] = gmean ? M[rl[m]] : 0.f;
+            }
+            float hi[RPL][NS], lo[RPL][NS];
+#pragma unroll
+            for (int m = 0; m < RPL; ++m)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) hi[m][s] = lo[m][s] = 0.f;
             for (int i = 0; i < k; ++i) {
@@ -378,7 +439,7 @@ __global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict
 #pragma unroll
                 for (int s = 0; s < NS; ++s) c[s] = C[i * NS + s];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < RPL; ++m) {
                     const float uv = u_val(Uh, rl[m] * k + i);
 #pragma unroll
                     for (int s = 0; s < NS; ++s) hi[m][s] = fmaf(uv, c[s], hi[m][s]);
@@ -389,14 +450,14 @@ __global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict
 #pragma unroll
                 for (int s = 0; s < NS; ++s) c[s] = C[(k + j) * NS + s];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < RPL; ++m) {
                     const float uv = u_val(Ul, rl[m] * nl + j);
 #pragma unroll
                     for (int s = 0; s < NS; ++s) lo[m][s] = fmaf(uv, c[s], lo[m][s]);
                 }
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < RPL; ++m) {
                 float acc = 0.f;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -409,18 +470,18 @@ __global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict
                         acc = v;
                     }
                 }
-                res[m] = cs.sel[m] ? acc : 0.f;
+                res[m] = sel[m] ? acc : 0.f;
             }
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (cs.in[m] && (cs.sel[m] || fill)) {
+        for (int m = 0; m < RPL; ++m) {
+            if (in[m] && (sel[m] || fill)) {
                 const float v = gbase ? __fadd_rn(bv[m], res[m]) : res[m];      // base + delta (merge.py:429-552)
                 gout[src + 64 * m + lane] = v;
             }
         }
         lds_fence();
-        cpos += cs.count;
+        cpos += count;
     }
 }
 
@@ -457,25 +518,6 @@ struct DiagPart {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) f32x2 mg_gf32x2;
 
-struct UStage {      // where a block's staged basis rows sit (wave-uniform)
-    int nvh, nv;     // 16-byte vectors of the U_high part, of both parts
-    int offh, offl;  // element offset of the block's first row inside each part
-    int64_t a0h, a0l;
-};
-template <int ES>
-__device__ __forceinline__ UStage ustage_plan(int64_t c0, int nr, int k, int nl) {
-    UStage u;
-    const int64_t b0h = c0 * k * ES, b1h = (c0 + nr) * (int64_t)k * ES;
-    const int64_t b0l = c0 * nl * ES, b1l = (c0 + nr) * (int64_t)nl * ES;
-    u.a0h = b0h & ~15ll;
-    u.a0l = b0l & ~15ll;
-    u.nvh = k > 0 ? (int)((b1h - u.a0h + 15) >> 4) : 0;
-    u.nv = u.nvh + (nl > 0 ? (int)((b1l - u.a0l + 15) >> 4) : 0);
-    u.offh = (int)(b0h - u.a0h) / ES;
-    u.offl = (int)(b0l - u.a0l) / ES;
-    return u;
-}
-
 __device__ __forceinline__ float lds_u(const uint8_t *base, int byte_off, __half) {
     return __half2float(*reinterpret_cast<const __half *>(base + byte_off));
 }
@@ -496,8 +538,13 @@ template <bool B> struct DiagBool { static constexpr bool value = B; };
 
 // FULL: the plan has exactly NTP tasks -- no "task t is real" tests (each one is a scalar-register pair the compiler
 // keeps across the loop; with twenty of them the task pointers are pushed out of the scalar registers)
+#ifdef SVDQ_DIAG_WPE
+#define SVDQ_DIAG_ATTR __attribute__((amdgpu_waves_per_eu(SVDQ_DIAG_WPE, SVDQ_DIAG_WPE)))
+#else
+#define SVDQ_DIAG_ATTR
+#endif
 template <int NTP, int RPL_, bool PACK2, bool FULL, bool U16, bool WALK>
-__global__ __launch_bounds__(64) void k_diag(const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
+__global__ __launch_bounds__(64) SVDQ_DIAG_ATTR void k_diag(const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
                                              const float *const *__restrict__ ptrs,
                                              const uint8_t *const *__restrict__ mask_ptrs,
                                              const int64_t *__restrict__ ustart, const int64_t *__restrict__ rows_dev,
@@ -737,8 +784,20 @@ __global__ __launch_bounds__(64) void k_diag(const SvdqParam *__restrict__ param
                         ua[s] += ust[s];
                     }
                 };
-                auto tile = [&](int ti, const float (&a)[KMAX], auto masked_c) {
+                auto tile = [&](int ti, const float (&a_in)[KMAX], auto masked_c) {
                     constexpr bool MASKED = decltype(masked_c)::value;
+                    float a[KMAX];
+#pragma unroll
+                    for (int s = 0; s < KMAX; ++s) {
+                        a[s] = a_in[s];
+                        if constexpr (MASKED) {
+                            // the block's last tile: rows past its count were never staged; whatever sits there must not
+                            // reach the matrix pipe -- a NaN times a zero coefficient is a NaN in a VALID row's sum (PACK2:
+                            // set B's rows feed set A's result columns through the zero blocks of C)
+                            const int arow = ti * TROWS + col + ((PACK2 && s >= 2) ? 16 : 0);
+                            a[s] = arow < count ? a[s] : 0.f;
+                        }
+                    }
                     const int rb = ti * TROWS + (PACK2 ? 16 * (col >> 3) : 0) + 4 * g;      // the lane's four rows
                     f32x4 x[TT], acc[TT];
 #pragma unroll
@@ -938,18 +997,35 @@ static int launch_reconstruct(const char *who, const svdq_plan *pl, const int64_
     auto mp = reinterpret_cast<const uint8_t *const *>(mask_ptrs);
     hipStream_t st = (hipStream_t)stream;
     const int ns = n_sets == 1 ? 1 : (n_sets == 2 ? 2 : (n_sets <= 4 ? 4 : 8));
-    const size_t lds = (size_t)SVDQ_BLK_ROWS * pl->n_tasks * (pl->cfg.fp16 ? 2 : 4) + (mp ? 64 : 0) +
-                       (size_t)(ns * pl->n_tasks + ns) * 4;
+    const int rpl = pl->n_tasks <= 8 ? 4 : (pl->n_tasks <= 16 ? 2 : 1);      // k_merge_reconstruct: rows per lane and block
+    const size_t lds = (size_t)svdq_align_up((int64_t)64 * rpl * pl->n_tasks * (pl->cfg.fp16 ? 2 : 4) + 48, 16) +
+                       (mp ? (size_t)64 * rpl * 4 : 0) + (size_t)(ns * pl->n_tasks + ns) * 4;
     const uint8_t *bs = reinterpret_cast<const uint8_t *>(basis);
     const float *mn = pl->cfg.center ? mean : nullptr;
 #define SVDQ_MRG_LAUNCH(F16, NS_)                                                                                      \
     do {                                                                                                               \
-        if (mp)                                                                                                        \
-            hipLaunchKernelGGL((k_merge_expand<F16, NS_>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,          \
+        if (mp && rpl == 4)                                                                                            \
+            hipLaunchKernelGGL((k_merge_expand<F16, NS_, 4>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,       \
                                pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
                                scale, mp, unit_start, fill, bp, op);                                                   \
+        else if (mp && rpl == 2)                                                                                       \
+            hipLaunchKernelGGL((k_merge_expand<F16, NS_, 2>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,       \
+                               pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
+                               scale, mp, unit_start, fill, bp, op);                                                   \
+        else if (mp)                                                                                                   \
+            hipLaunchKernelGGL((k_merge_expand<F16, NS_, 1>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,       \
+                               pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
+                               scale, mp, unit_start, fill, bp, op);                                                   \
+        else if (rpl == 4)                                                                                             \
+            hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_, 4>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,  \
+                               pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
+                               scale, bp, op);                                                                         \
+        else if (rpl == 2)                                                                                             \
+            hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_, 2>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,  \
+                               pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
+                               scale, bp, op);                                                                         \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,     \
+            hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_, 1>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,  \
                                pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
                                scale, bp, op);                                                                         \
     } while (0)

@@ -117,3 +117,33 @@ def diag_check(got, x, U_high, U_low, c_high, c_low, what="", mean=None, slack=1
     for key in orc.DIAG_KEYS:
         g, w = float(got[key]), float(want[key])
         assert abs(g - w) <= 2e-6 * abs(w) + slack * tol[key] + 1e-30, (what, key, g, w, tol[key])
+
+
+def diag_check_chunked(got, x, U_high, U_low, c_high, c_low, what="", chunk=1 << 24):
+    """diag_check for tensors too long for one library call (2^30 rows: a single fp64 matrix-vector product of that
+    length is itself suspect): the same formula and the same bound, accumulated over row chunks in fp64."""
+    import math
+    import torch
+    c = torch.cat([c_high.double().reshape(-1), c_low.double().reshape(-1)])
+    ca = c.abs()
+    D = x.numel()
+    se = sx = sr = sa = mx = a2 = a1 = amax = 0.0
+    for lo in range(0, D, chunk):
+        sl = slice(lo, min(lo + chunk, D))
+        U = torch.cat([U_high[sl].double(), U_low[sl].double()], dim=1)
+        rec = (U * c).sum(dim=1)      # elementwise: a library matrix-vector product refuses / mishandles this many rows
+        xs = x[sl].double().reshape(-1)
+        e = xs - rec
+        A = (U.abs() * ca).sum(dim=1)
+        se += float((e * e).sum()); sx += float((xs * xs).sum()); sr += float((rec * rec).sum())
+        sa += float(e.abs().sum()); mx = max(mx, float(e.abs().max()))
+        a2 += float((A * A).sum()); a1 += float(A.sum()); amax = max(amax, float(A.max()))
+    g = (U_high.shape[1] + U_low.shape[1] + 2) * 2.0 ** -24
+    xn = math.sqrt(sx)
+    want = {"absolute_error": math.sqrt(se), "relative_error": math.sqrt(se) / xn if xn > 1e-10 else 0.0,
+            "max_absolute_error": mx, "mean_absolute_error": sa / D, "original_norm": xn, "reconstructed_norm": math.sqrt(sr)}
+    tol = {"absolute_error": math.sqrt(a2) * g, "relative_error": math.sqrt(a2) * g / xn if xn > 1e-10 else 0.0,
+           "max_absolute_error": amax * g, "mean_absolute_error": a1 / D * g, "original_norm": 0.0,
+           "reconstructed_norm": math.sqrt(a2) * g}
+    for key, w in want.items():
+        assert abs(float(got[key]) - w) <= 2e-6 * abs(w) + tol[key] + 1e-30, (what, key, float(got[key]), w, tol[key])

@@ -82,7 +82,7 @@ def test_plan_diagnostics_vs_fp64_oracle(sq, n_tasks, fp16, center):
     from svdq_amd import diagnostics as dg
     from svdq_amd.pipeline import CompressPlan
     dev = torch.device("cuda", 0)
-    sizes = [9000, 257, 4096 * 3 + 5, 1, 8192 + 300]
+    sizes = [9000, 257, 4096 * 3 + 5, 1, 8192 + 300, 13, 40, 17]      # short last tiles after long parameters: stale LDS behind them
     gen = torch.Generator().manual_seed(n_tasks)
     vecs = [[d.clone() for d in orc.synthetic_deltas(D, n_tasks, 300 + i, rank=3)] for i, D in enumerate(sizes)]
     vecs = [[d.to(dev) for d in vs] for vs in _spiked(vecs, sizes, gen)]
@@ -119,8 +119,8 @@ def test_masked_plan_diagnostics_vs_fp64_oracle(sq, n_tasks, fp16, inverted):
     from svdq_amd.mask_loader import MaskSet
     from svdq_amd.pipeline import CompressPlan
     dev = torch.device("cuda", 0)
-    sizes = [9000, 300, 4096 * 3 + 5, 8192 + 300]
-    dens = [0.9, 0.5, 0.97, 0.15]
+    sizes = [9000, 300, 4096 * 3 + 5, 8192 + 300, 61, 150]
+    dens = [0.9, 0.5, 0.97, 0.15, 0.3, 0.8]
     gen = torch.Generator().manual_seed(100 + n_tasks)
     vecs = [[d.clone() for d in orc.synthetic_deltas(D, n_tasks, 500 + i, rank=3)] for i, D in enumerate(sizes)]
     vecs = [[d.to(dev) for d in vs] for vs in _spiked(vecs, sizes, gen)]

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import bits_equal
+from helpers import bits_equal, diag_check, diag_check_chunked
 
 pytestmark = pytest.mark.gpu
 
@@ -164,8 +164,9 @@ def test_full_model_masked_consumers_in_the_streaming_launches():
     """The consumers of BASELINE configs[2] at full size (ViT-B-16 x 8, union mask, mask-walk compression): the merge with
     the mask scatter inside the streaming launch (svdq_merge_masked, + base) against merging in the compacted row
     space and expanding with torch's own boolean assignment -- bit for bit on every tensor; and the masked plan-level
-    diagnostics against the per-call fused error on torch's own `x[mask]` for two tensors."""
+    diagnostics against the reference's formula in fp64 on torch's own `x[mask]` for two tensors."""
     import svdq_amd
+    from oracle import svd_hybrid_oracle as orc
     from svdq_amd import workloads
     from svdq_amd.mask_loader import MaskSet
     from svdq_amd.pipeline import CompressPlan
@@ -205,14 +206,13 @@ def test_full_model_masked_consumers_in_the_streaming_launches():
         mask = comb[p].view(torch.bool)
         k, r_ = int(sm.k[p]), int(sm.r[p])
         Uh, Ul, _ = plan.basis_tensors(p, k, r_, int(sm.rows[p]))
-        quant = svdq_amd.RTVQQuantizer(4, 4)
         for t in (0, 5):
-            art = svdq_amd.pipeline.task_artifact(plan, sm, p, t)
-            cl = quant.dequantize(art["c_low_quant"], device=dev).float()
-            ref6 = svdq_amd.diagnostics._fused_error(views[p][t][mask].contiguous(), Uh, Ul,
-                                                     art["c_high_fp16"].to(dev).float(), cl, dev)
-            for j, key in enumerate(svdq_amd.diagnostics._KEYS):
-                assert res[p, t, j] == pytest.approx(ref6[key], rel=1e-6, abs=1e-12), (want_name, t, key)
+            # diagnostics.py:186-215 in fp64 (torch, on the device: 2.4 M rows) on the plan's own artifacts -- the basis
+            # as stored, fp16 c_high, the codes dequantized by the oracle -- and torch's own x[mask]
+            ch = torch.from_numpy(sm.c_high[p, t, :k].astype(np.float32)).to(dev)
+            cl = torch.from_numpy(orc.rtvq_dequantize({"codes": sm.codes[p, t, :, :r_ - k], "scale": sm.scale[p, t],
+                                                       "zero_point": sm.zero_point[p, t]}).reshape(-1).copy()).to(dev)
+            diag_check(dict(zip(orc.DIAG_KEYS, res[p, t])), views[p][t][mask], Uh, Ul, ch, cl, what=(want_name, t))
 
 
 def test_config5_vitl14_x20_mixed_widths_cluster_merge():
@@ -384,7 +384,7 @@ def test_single_tensor_beyond_2_pow_30_rows():
         Us = torch.cat([U_high[sl], U_low[sl]], dim=1).float()
         assert float((Us @ coef.T + ms - Xs).abs().max()) < 2e-3 * scale
     # the plan-level consumers at this size (64-bit offsets in k_merge_reconstruct / k_diag): the merge against torch on
-    # slices at both ends and across row 2^30, the diagnostics against the per-call fused error of one task
+    # slices at both ends and across row 2^30, the diagnostics of one task against the reference's formula in fp64
     import svdq_amd
     w = torch.tensor([[0.5, 0.3, 0.2]], device=dev)
     buf, offs = plan.merge(w)
@@ -400,9 +400,10 @@ def test_single_tensor_beyond_2_pow_30_rows():
         want = Us @ cbar + mean[sl].flatten()
         assert torch.allclose(buf[offs[0] + lo:offs[0] + lo + 5000], want, rtol=1e-4, atol=1e-5 * scale)
     res = plan.diagnostics(plan.pointer_table([vecs])).cpu().numpy()
-    ref6 = svdq_amd.diagnostics._fused_error(vecs[1], U_high, U_low, cs[1][:k], cs[1][k:], dev)
-    for j, key in enumerate(svdq_amd.diagnostics._KEYS):
-        assert res[0, 1, j] == pytest.approx(ref6[key], rel=1e-6, abs=1e-12), key
+    from oracle import svd_hybrid_oracle as orc
+    c1 = torch.from_numpy(np.concatenate([sm.c_high[0, 1, :k].astype(np.float32), orc.rtvq_dequantize(
+        {"codes": sm.codes[0, 1, :, :r - k], "scale": sm.scale[0, 1], "zero_point": sm.zero_point[0, 1]}).reshape(-1)])).to(dev)
+    diag_check_chunked(dict(zip(orc.DIAG_KEYS, res[0, 1])), vecs[1], U_high, U_low, c1[:k], c1[k:], what="2^30 rows")   # fp64, on the device
 
 
 def test_quantizer_beyond_2_pow_31_elements():

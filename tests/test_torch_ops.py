@@ -168,6 +168,8 @@ def test_masked_from_base_and_consumer_ops_match_the_ctypes_route():
     e6 = torch.ops.svdq.recon_error(Uh, Ul, coef, None, x)
     ref6 = svdq_amd.diagnostics._fused_error(x, Uh, Ul, coef[:k], coef[k:], dev)
     assert [float(v) for v in e6.cpu()] == [ref6[key] for key in svdq_amd.diagnostics._KEYS]
+    from helpers import diag_check      # and the operator's numbers against diagnostics.py:186-215 in fp64 on the same operands
+    diag_check(ref6, x.cpu(), Uh.cpu(), Ul.cpu(), coef[:k].cpu(), coef[k:].cpu(), what="torch.ops.svdq.recon_error")
     # the plan-level merge on the buffers the compress operator returned
     w = torch.tensor([0.3, 0.1, 0.2, 0.15, 0.05, 0.2], device=dev)
     outs = torch.ops.svdq.merge(small, basis, mean, sizes, N, 0.9, 0, True, True, 4, 2, w, base)
