@@ -111,8 +111,8 @@ __device__ __forceinline__ UStage ustage_plan(int64_t c0, int nr, int k, int nl)
     return u;
 }
 
-// One wavefront per work unit of the plan.  Blocks of RB = 64 RPL rows (256 for N <= 8, 128 for N <= 16, 64 above: the
-// block's basis rows then fit the same few registers per lane); lane l owns rows l, 64 + l, ... of a block (conflict-free
+// One wavefront per work unit of the plan.  Blocks of RB = 64 RPL rows (256 for N <= 16, 128 above: the block's basis
+// rows then fit 9 (fp16) / 17 (fp32) 16-byte registers per lane); lane l owns rows l, 64 + l, ... of a block (conflict-free
 // row reads from the row-major LDS image).  Software pipeline, one block deep: while block b is computed from LDS, the
 // loads of block b + 1 -- its run of basis rows (16-byte loads), its mean and base rows -- are in flight into registers
 // (round 3 loaded a tile, fenced, computed, fenced: nothing was in flight during the compute phase and the counters showed
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64) void k_merge_reconstruct(const SvdqParam *__res
     using T = typename UElem<U16>::type;
     constexpr int ES = U16 ? 2 : 4;
     constexpr int RB = 64 * RPL;
-    constexpr int NMAX = RPL == 4 ? 8 : (RPL == 2 ? 16 : 32);       // tasks this block size is launched for
+    constexpr int NMAX = RPL == 4 ? 16 : 32;                          // tasks this block size is launched for
     constexpr int SV = (RB * NMAX * ES / 16 + 2 + 63) / 64;          // 16-byte vectors of one block's basis rows per lane
     // dynamic LDS: the staged basis rows (both parts + alignment slack), then the coefficient sets
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -284,7 +284,7 @@ __device__ __forceinline__ SrcRange unit_source_range(const SvdqParam &pd, int u
     return s;
 }
 
-// One wavefront per work unit; chunk = RB = 64 RPL SOURCE rows (256 for N <= 8, 128 for N <= 16, 64 above), lane l owns rows
+// One wavefront per work unit; chunk = RB = 64 RPL SOURCE rows (256 for N <= 16, 128 above), lane l owns rows
 // src + 64 e + l.  The same one-block software pipeline as k_merge_reconstruct: while chunk c is computed from LDS, chunk
 // c + 1's mask bytes and base rows and -- from the compacted position where chunk c ends, known once c's mask has been
 // counted -- the next RB basis rows and mean values (clamped to the unit; how many of them chunk c + 1 selects is not
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void k_merge_expand(const SvdqParam *__restrict
     using T = typename UElem<U16>::type;
     constexpr int ES = U16 ? 2 : 4;
     constexpr int RB = 64 * RPL;
-    constexpr int NMAX = RPL == 4 ? 8 : (RPL == 2 ? 16 : 32);
+    constexpr int NMAX = RPL == 4 ? 16 : 32;
     constexpr int SV = (RB * NMAX * ES / 16 + 2 + 63) / 64;
     // dynamic LDS: the staged basis rows, the staged mean values, the coefficient sets
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -997,7 +997,7 @@ static int launch_reconstruct(const char *who, const svdq_plan *pl, const int64_
     auto mp = reinterpret_cast<const uint8_t *const *>(mask_ptrs);
     hipStream_t st = (hipStream_t)stream;
     const int ns = n_sets == 1 ? 1 : (n_sets == 2 ? 2 : (n_sets <= 4 ? 4 : 8));
-    const int rpl = pl->n_tasks <= 8 ? 4 : (pl->n_tasks <= 16 ? 2 : 1);      // k_merge_reconstruct: rows per lane and block
+    const int rpl = pl->n_tasks <= 16 ? 4 : 2;      // rows per lane and block (256 / 128 rows: a block's basis rows stay <= 17 vectors per lane)
     const size_t lds = (size_t)svdq_align_up((int64_t)64 * rpl * pl->n_tasks * (pl->cfg.fp16 ? 2 : 4) + 48, 16) +
                        (mp ? (size_t)64 * rpl * 4 : 0) + (size_t)(ns * pl->n_tasks + ns) * 4;
     const uint8_t *bs = reinterpret_cast<const uint8_t *>(basis);
@@ -1008,24 +1008,16 @@ static int launch_reconstruct(const char *who, const svdq_plan *pl, const int64_
             hipLaunchKernelGGL((k_merge_expand<F16, NS_, 4>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,       \
                                pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
                                scale, mp, unit_start, fill, bp, op);                                                   \
-        else if (mp && rpl == 2)                                                                                       \
-            hipLaunchKernelGGL((k_merge_expand<F16, NS_, 2>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,       \
-                               pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
-                               scale, mp, unit_start, fill, bp, op);                                                   \
         else if (mp)                                                                                                   \
-            hipLaunchKernelGGL((k_merge_expand<F16, NS_, 1>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,       \
+            hipLaunchKernelGGL((k_merge_expand<F16, NS_, 2>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,       \
                                pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
                                scale, mp, unit_start, fill, bp, op);                                                   \
         else if (rpl == 4)                                                                                             \
             hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_, 4>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,  \
                                pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
                                scale, bp, op);                                                                         \
-        else if (rpl == 2)                                                                                             \
-            hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_, 2>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,  \
-                               pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
-                               scale, bp, op);                                                                         \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_, 1>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,  \
+            hipLaunchKernelGGL((k_merge_reconstruct<F16, NS_, 2>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params,  \
                                pl->d_units, rows_dev, pl->n_tasks, n_sets, per_param, kk, rr, bs, mn, cbar, set_share,  \
                                scale, bp, op);                                                                         \
     } while (0)

@@ -428,8 +428,27 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> compress_gather(at::T
                                "compress_gather");
 }
 
+// the packed buffers a consumer operator is handed must be the ones a plan with these settings wrote: on the
+// operator's device, contiguous, of the plan's sizes -- a short or foreign `mean` would otherwise be read out of bounds by
+// the streaming kernels instead of raising here
+static void check_artifacts(const char *what, const at::Tensor &small, const at::Tensor &basis, const at::Tensor &mean,
+                            const svdq_sizes &sz, bool center, const c10::Device &dev) {
+    TORCH_CHECK_VALUE(small.device() == dev && basis.device() == dev, what, ": all tensors must live on one device");
+    TORCH_CHECK_VALUE(small.is_contiguous() && basis.is_contiguous(), what, ": small / basis must be contiguous");
+    TORCH_CHECK_VALUE((int64_t)small.nbytes() == sz.small_bytes && (int64_t)basis.nbytes() >= sz.basis_bytes, what,
+                      ": small / basis are not the buffers of a plan with these rows and settings");
+    if (center) {
+        TORCH_CHECK_VALUE(mean.defined() && mean.device() == dev && mean.scalar_type() == at::kFloat && mean.is_contiguous() &&
+                              mean.numel() >= sz.mean_floats,
+                          what, ": mean must be the plan's float32 mean buffer (", sz.mean_floats,
+                          " floats, contiguous, on the same device) when center is set");
+    }
+}
+
 // svdq_merge on the buffers `compress` returned for the same rows / settings: merged delta of every parameter
-// (weights float32 [n_tasks] or [n_sets, n_tasks] with shares = uniform over sets when more than one), + base when given
+// (weights float32 [n_tasks] or [n_sets, n_tasks] with shares = uniform over sets when more than one), + base when given.
+// The weights are used AS GIVEN (the kernel adds w_t c_t over the tasks): like merge.py:123-124 the caller renormalises
+// them over the tasks that are present; a negative entry marks a task that is not in the set.
 std::vector<at::Tensor> merge(const at::Tensor &small, const at::Tensor &basis, const at::Tensor &mean,
                               at::IntArrayRef rows_in, int64_t n_tasks, double energy, int64_t max_rank, bool center,
                               bool fp16, int64_t bits, int64_t stages, const at::Tensor &weights, at::TensorList base) {
@@ -447,8 +466,7 @@ std::vector<at::Tensor> merge(const at::Tensor &small, const at::Tensor &basis, 
     PlanKey key{rows, n_tasks, max_rank, bits, stages, energy, center, fp16, (int)dev.index(), stream};
     std::lock_guard<std::mutex> lock(g_cache_mu);
     std::unique_ptr<Plan> plan = acquire_plan(key, dev);
-    TORCH_CHECK_VALUE(small.numel() == plan->sizes.small_bytes && basis.numel() >= plan->sizes.basis_bytes,
-                      "merge: small / basis are not the buffers of a plan with these rows and settings");
+    check_artifacts("merge", small, basis, mean, plan->sizes, center, dev);
     std::vector<at::Tensor> outs, bs;
     for (int64_t p = 0; p < P; ++p) outs.push_back(floats_on(dev, rows[p]));
     for (size_t p = 0; p < base.size(); ++p) {
@@ -533,8 +551,7 @@ std::vector<at::Tensor> merge_masked(const at::Tensor &small, const at::Tensor &
     PlanKey key{rows, n_tasks, max_rank, bits, stages, energy, center, fp16, (int)dev.index(), stream};
     std::lock_guard<std::mutex> lock(g_cache_mu);
     std::unique_ptr<Plan> plan = acquire_plan(key, dev);
-    TORCH_CHECK_VALUE(small.numel() == plan->sizes.small_bytes && basis.numel() >= plan->sizes.basis_bytes,
-                      "merge_masked: small / basis are not the buffers of a plan with these masks and settings");
+    check_artifacts("merge_masked", small, basis, mean, plan->sizes, center, dev);
     MaskWalk mw = mask_walk(ms, *plan, masks, rows, dev, stream, "merge_masked");
     std::vector<at::Tensor> outs, bs;
     for (int64_t p = 0; p < P; ++p) outs.push_back(floats_on(dev, rows[p]));
@@ -586,8 +603,7 @@ at::Tensor diagnostics(at::TensorList deltas, at::TensorList masks, const at::Te
     PlanKey key{rows, n_tasks, max_rank, bits, stages, energy, center, fp16, (int)dev.index(), stream};
     std::lock_guard<std::mutex> lock(g_cache_mu);
     std::unique_ptr<Plan> plan = acquire_plan(key, dev);
-    TORCH_CHECK_VALUE(small.numel() == plan->sizes.small_bytes && basis.numel() >= plan->sizes.basis_bytes,
-                      "diagnostics: small / basis are not the buffers of a plan with these tensors and settings");
+    check_artifacts("diagnostics", small, basis, mean, plan->sizes, center, dev);
     at::Tensor table = table_of(vecs, dev);
     at::Tensor out = at::empty({P, n_tasks, 6}, at::TensorOptions().dtype(at::kDouble).device(dev));
     at::Tensor work = bytes_on(dev, svdq_diagnostics_work_bytes(plan->h));

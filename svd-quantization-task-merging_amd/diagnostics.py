@@ -137,8 +137,13 @@ def _batched_errors(task_vectors, compressed_all, bases, masks) -> Dict[str, Dic
             if mask is not None:
                 continue
         elif (mask is None or batch.unit_start is None
-              or getattr(batch, "mask_ident", {}).get(name) != _mask_identity(mask)):
-            continue      # the selection is made with the mask the run compressed with
+              or getattr(batch, "mask_ident", {}).get(name) != _mask_identity(mask)
+              or any(t in task_vectors and name in task_vectors[t] and mask.shape != task_vectors[t][name].shape
+                     for t in batch.task_names[i])):
+            # the selection is made with the mask the run compressed with (the SAME tensor: its bytes must not have been
+            # edited in place since -- the unit starts date from the compression), and like the reference
+            # (diagnostics.py:193-198) only when the mask has the delta's shape; anything else: per-parameter route
+            continue
         # the error is measured against the tensors the CALLER passes: they must be the ones the plan still points at
         kept = batch.plan._keep[i] if batch.plan._keep is not None else None
         tasks_i = batch.task_names[i]

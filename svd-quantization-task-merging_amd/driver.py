@@ -215,12 +215,21 @@ class LazyArtifacts(dict):
         return super().__repr__()
 
 
+_MUTATORS = frozenset(("__setitem__", "__delitem__", "__ior__", "pop", "popitem", "setdefault", "update", "clear"))
+
+
 def _lazy(name):
     def method(self, *a, **kw):
         self._ensure()
         for x in a:      # dict.__eq__ / __or__ / update read the OTHER operand through the C dict API, past its wrappers
             if isinstance(x, LazyArtifacts):
                 x._ensure()
+        if name in _MUTATORS:
+            # an edited dictionary no longer describes the buffers of the fused run: the batched consumers (svdq_merge,
+            # svdq_diagnostics) must not answer for it from there -- they fall back to the per-parameter route, which
+            # reads the dictionary as the reference does
+            self._batch = None
+            self._meta = None
         return getattr(dict, name)(self, *a, **kw)
     method.__name__ = name
     return method

@@ -118,15 +118,45 @@ def merge_parameter(param_name: str, compressed_params: Dict[str, Dict], basis: 
 
 
 def _batched_entry(name, compressed_all, bases):
-    """(plan batch, index, meta) when both dictionaries of ``name`` still are what the fused run handed out."""
+    """(plan batch, index, meta) when both dictionaries of ``name`` still are what the fused run handed out: the
+    LazyArtifacts themselves drop their handle on any edit through them; what an edit can reach WITHOUT going through
+    them is checked here -- the noise entry of the (plain) per-parameter basis dictionary, and, once a compressed entry
+    has been materialised, the per-task dictionaries it handed out (a deleted task, an artifact replaced or set to
+    None).  In-place edits of payload tensors are not detectable; the reference has no such use."""
     from .driver import LazyArtifacts
+    from .pipeline import task_artifact
     b, ca = bases.get(name), compressed_all.get(name)
     bm = b.get("masked") if isinstance(b, dict) else None
-    if (isinstance(bm, LazyArtifacts) and bm._batch is not None and isinstance(ca, LazyArtifacts)
+    if not (isinstance(bm, LazyArtifacts) and bm._batch is not None and isinstance(ca, LazyArtifacts)
             and ca._meta is not None and ca._batch is not None and ca._batch[0] is bm._batch[0]
             and ca._batch[1] == bm._batch[1]):
-        return bm._batch[0], bm._batch[1], ca._meta
-    return None
+        return None
+    meta = ca._meta
+    bn = b.get("noise")
+    if meta["noise"] is not None:
+        if not (isinstance(bn, LazyArtifacts) and bn._batch is not None and bn._batch[0] is meta["noise"][0]
+                and bn._batch[1] == meta["noise"][1]):
+            return None
+    elif bn is not None:
+        return None
+    if ca._fill is None:      # materialised: somebody may hold (and have edited) the per-task dictionaries
+        batch, i = bm._batch
+        if list(dict.keys(ca)) != list(meta["have"]):
+            return None
+        pos = {t: j for j, t in enumerate(batch.task_names[i])}
+        npos = None
+        if meta["noise"] is not None:
+            nb, j = meta["noise"]
+            npos = {t: q for q, t in enumerate(nb.task_names[j])}
+        for t in meta["have"]:
+            art = dict.__getitem__(ca, t)
+            if not isinstance(art, dict) or set(art.keys()) != {"masked", "unmasked"}:
+                return None
+            want_m = task_artifact(batch.plan, batch.small, i, pos[t]) if t in pos else None
+            want_u = task_artifact(nb.plan, nb.small, j, npos[t]) if (npos is not None and t in npos) else None
+            if art["masked"] is not want_m or art["unmasked"] is not want_u:
+                return None
+    return bm._batch[0], bm._batch[1], meta
 
 
 def _task_weights(have, tasks_i, members, weights):
@@ -218,13 +248,18 @@ def _merge_batched(names, compressed_all, bases, masks, sets, original_shapes, c
             sc_d = torch.from_numpy(scale).to(plan.device)
             sh_d = None
             if S > 1:
-                # apply_weights_to_tensors (weighting.py:332-372): shares renormalised over the sets a parameter has
+                # merge_with_clustering (merge.py:555-626) merges EVERY parameter inside every cluster -- a cluster none of
+                # whose members has it contributes merge_parameter's zeros (merge.py:297-299) -- so
+                # apply_weights_to_tensors (weighting.py:332-372) normalises the shares over ALL clusters, and a
+                # parameter only some clusters hold comes out scaled by the sum of THEIR shares (its mean included):
+                # shares / shares.sum() for the sets that have it, "skip" (-1) for the others -- no renormalisation
                 ok = torch.from_numpy(share_ok).to(plan.device)
-                sh = torch.where(ok, shares.to(plan.device).view(1, S).expand(P, S), torch.zeros((), device=plan.device))
-                tot = torch.zeros(P, dtype=torch.float32, device=plan.device)
+                sh = shares.to(plan.device).view(S)
+                tot = torch.zeros((), dtype=torch.float32, device=plan.device)
                 for s_ in range(S):      # w.sum() of <= 8 values, in set order
-                    tot = tot + sh[:, s_]
-                sh_d = torch.where(ok, sh / tot.view(P, 1), torch.full((), -1.0, device=plan.device)).contiguous()
+                    tot = tot + sh[s_]
+                sh_d = torch.where(ok, (sh / tot).view(1, S).expand(P, S),
+                                   torch.full((), -1.0, device=plan.device)).contiguous()
             rows_dev = plan.small[plan.layout.rows_off:plan.layout.rows_off + 8 * P].view(torch.int64)
             mine = {i: e for i, e in entries.items() if live.get(e[0], {}).get(e[1]) == (key, i)}
             take = {i: e for i, e in mine.items() if e[0] in fused}
@@ -240,7 +275,10 @@ def _merge_batched(names, compressed_all, bases, masks, sets, original_shapes, c
                                   torch.from_numpy(out_tab).to(plan.device), order=ord_d, set_share=sh_d, scale=sc_d,
                                   fill=torch.from_numpy(fill).to(plan.device))
             if len(take) < len(mine):
-                buf, offs = plan.merge(wt_d, order=ord_d, set_share=sh_d, scale=sc_d, rows_dev=rows_dev)
+                # a buffer of this call's own: the reference returns fresh tensors, and a later merge of the same plan
+                # (other weights, an ablation) must not overwrite what this one handed out
+                buf, offs, otab = plan.new_merged_outputs()
+                plan.merge(wt_d, order=ord_d, set_share=sh_d, scale=sc_d, rows_dev=rows_dev, out_table=otab)
                 for i, (name, region, meta) in mine.items():
                     if i not in take:
                         pieces.setdefault(name, {})[region] = buf[offs[i]:offs[i] + int(small.rows[i])]

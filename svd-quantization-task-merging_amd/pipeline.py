@@ -277,19 +277,26 @@ class CompressPlan:
                                                           _stream_ptr()), "svdq_compress_gather_from_base")
 
     # ---- consumers of the artifacts, batched over the plan (svdq_merge.hip)
-    def merged_outputs(self):
-        """One packed fp32 buffer for the merged rows of every parameter (64-float aligned slices) + its device
-        pointer table; allocated on first use and reused by later merges of this plan."""
-        mo = getattr(self, "_merged", None)
-        if mo is None:
+    def new_merged_outputs(self):
+        """One packed fp32 buffer for the merged rows of every parameter (64-float aligned slices), its offsets and its
+        device pointer table -- a fresh allocation per call (what the dictionary API hands to its caller)."""
+        lay = getattr(self, "_merged_layout", None)
+        if lay is None:
             offs, tot = [], 0
             for r in self.rows:
                 offs.append(tot)
                 tot += (r + 63) // 64 * 64
-            buf = torch.empty(tot, dtype=torch.float32, device=self.device)
-            base = buf.data_ptr()
-            table = torch.tensor([base + 4 * o for o in offs], dtype=torch.int64).to(self.device)
-            mo = self._merged = (buf, offs, table)
+            lay = self._merged_layout = (offs, tot, torch.tensor(offs, dtype=torch.int64).to(self.device) * 4)
+        offs, tot, byte_offs = lay
+        buf = torch.empty(tot, dtype=torch.float32, device=self.device)
+        return buf, offs, byte_offs + buf.data_ptr()      # device-side add: no host table per call
+
+    def merged_outputs(self):
+        """The same, allocated on first use and REUSED by later merges of this plan (benchmarks, callers that consume
+        the result before merging again)."""
+        mo = getattr(self, "_merged", None)
+        if mo is None:
+            mo = self._merged = self.new_merged_outputs()
         return mo
 
     def merge(self, weights: torch.Tensor, order: Optional[torch.Tensor] = None, set_share: Optional[torch.Tensor] = None,

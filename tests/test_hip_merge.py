@@ -360,6 +360,112 @@ def test_batched_merge_is_the_per_parameter_merge(sq, with_masks, include_noise)
         assert _same_bits(cf[n], cs[n]), n
 
 
+def test_cluster_merge_when_a_whole_cluster_lacks_a_parameter(sq):
+    """merge_with_clustering (reference merge.py:555-626) merges every parameter inside every cluster; a cluster none of
+    whose members holds it contributes zeros and the cluster shares are normalised over ALL clusters
+    (weighting.py:332-372) -- so such a parameter (a per-task head) comes out scaled by the shares of the clusters that
+    do hold it, mean included.  The batched route must give the plain-dictionary route's bits (round-3 advice: it
+    renormalised over the holding clusters instead)."""
+    from oracle import svd_hybrid_oracle as orc
+    tasks = ["zeta", "alpha", "mid", "beta", "omega", "psi", "chi"]
+    assign = {"zeta": 1, "alpha": 0, "mid": 1, "beta": 0, "omega": 1, "psi": 1, "chi": 1}
+    tv, masks, shapes = _model_like(orc, tasks, False)
+    for t in ("alpha", "beta"):                                             # cluster 0 = {alpha, beta}: nobody has 'blk.0.b'
+        del tv[t]["blk.0.b"]
+    del tv["mid"]["emb"]                                                    # and one member of cluster 1 lacks 'emb'
+    cfg = sq.SVDHybridConfig(tasks=tasks, svd_energy_threshold=0.9, svd_max_rank=2, svd_low_bits=4, svd_rtvq_stages=3,
+                             svd_center=True)
+    weights = {"zeta": 0.3, "alpha": 0.1, "mid": 0.2, "beta": 0.05, "omega": 0.15, "psi": 0.1, "chi": 0.1}
+    bases, comp = sq.run_basis_and_compress(tv, None, cfg, "cuda")
+    plain = {n: {t: dict(a) if a is not None else None for t, a in v.items()} for n, v in comp.items()}
+    from svdq_amd import merge as mg
+    members = {1: [t for t in tasks if assign[t] == 1], 0: [t for t in tasks if assign[t] == 0]}
+    fast = mg._merge_with_clustering_batched(comp, bases, {}, weights, members, shapes, cfg, "cuda")
+    assert fast is not None and sorted(fast) == sorted(shapes)
+    slow = sq.merge_with_clustering(plain, bases, {}, weights, assign, shapes, cfg, device="cuda")
+    for n in shapes:
+        assert _same_bits(fast[n], slow[n]), n
+    # 'blk.0.b' is held by cluster 1 only: the result is share_1 x (cluster 1's merge), not the merge itself
+    only1 = sq.merge_all_parameters({n: {t: a for t, a in v.items() if assign[t] == 1} for n, v in plain.items()}, bases, {},
+                                    {t: weights[t] for t in tasks if assign[t] == 1}, shapes, cfg, device="cuda", verbose=False)
+    a, b = fast["blk.0.b"].double(), only1["blk.0.b"].double()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    ratio = float((a * b).sum() / (b * b).sum())
+    perf = {c: np.mean([weights[t] for t in tasks if assign[t] == c]) for c in (0, 1)}
+    share1 = float(np.exp(perf[1]) / (np.exp(perf[0]) + np.exp(perf[1])))
+    assert ratio == pytest.approx(share1, rel=1e-5) and share1 < 0.6
+
+
+def test_merged_tensors_are_the_callers_own(sq):
+    """The reference returns fresh tensors: a second merge of the same artifacts (other weights) must not change what
+    the first one returned (round-3 advice: the batched route handed out views of a buffer cached on the plan)."""
+    from oracle import svd_hybrid_oracle as orc
+    tasks = ["a", "b", "c", "d"]
+    tv, masks, shapes = _model_like(orc, tasks, True)
+    cfg = sq.SVDHybridConfig(tasks=tasks, svd_energy_threshold=0.9, svd_max_rank=2, svd_low_bits=4, svd_rtvq_stages=2)
+    bases, comp = sq.run_basis_and_compress(tv, masks, cfg, "cuda")
+    w1 = {"a": 0.7, "b": 0.1, "c": 0.1, "d": 0.1}
+    w2 = {"a": 0.1, "b": 0.1, "c": 0.1, "d": 0.7}
+    first = sq.merge_all_parameters(comp, bases, masks, w1, shapes, cfg, device="cuda", verbose=False)
+    keep = {n: v.clone() for n, v in first.items()}
+    second = sq.merge_all_parameters(comp, bases, masks, w2, shapes, cfg, device="cuda", verbose=False)
+    assign = {"a": 0, "b": 0, "c": 1, "d": 1}
+    third = sq.merge_with_clustering(comp, bases, masks, w1, assign, shapes, cfg, device="cuda")
+    torch.cuda.synchronize()
+    for n in shapes:
+        assert _same_bits(first[n], keep[n]), n
+        assert first[n].data_ptr() not in (second[n].data_ptr(), third[n].data_ptr())
+        assert not torch.equal(first[n].nan_to_num(), second[n].nan_to_num()), n
+
+
+def test_edited_dictionaries_leave_the_batched_route(sq):
+    """The batched consumers answer from the buffers of the fused run; a caller who edits the dictionaries (drops a
+    task, removes an artifact, switches the noise region off, swaps a basis entry) must get what the reference computes
+    from the EDITED dictionaries (round-3 advice: the edits were ignored)."""
+    from oracle import svd_hybrid_oracle as orc
+    from svdq_amd import merge as mg
+    tasks = ["a", "b", "c", "d", "e"]
+    weights = {t: 0.2 for t in tasks}
+
+    def fresh(include_noise=False):
+        tv, masks, shapes = _model_like(orc, tasks, include_noise)
+        cfg = sq.SVDHybridConfig(tasks=tasks, svd_energy_threshold=0.9, svd_max_rank=2, svd_low_bits=4, svd_rtvq_stages=2,
+                                 svd_include_noise=include_noise, svd_min_mask_size=10)
+        bases, comp = sq.run_basis_and_compress(tv, masks or None, cfg, "cuda")
+        return tv, masks, shapes, cfg, bases, comp
+
+    def plain_of(comp):
+        return {n: {t: (dict(a) if a is not None else None) for t, a in v.items()} for n, v in comp.items()}
+
+    # 1. a task deleted from one parameter
+    tv, masks, shapes, cfg, bases, comp = fresh()
+    assert mg._batched_entry("blk.0.w", comp, bases) is not None
+    del comp["blk.0.w"]["c"]
+    assert mg._batched_entry("blk.0.w", comp, bases) is None and mg._batched_entry("blk.0.b", comp, bases) is not None
+    got = sq.merge_all_parameters(comp, bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
+    want = sq.merge_all_parameters(plain_of(comp), bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
+    assert all(_same_bits(got[n], want[n]) for n in shapes)
+    full = sq.merge_all_parameters(plain_of(fresh()[5]), bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
+    assert not torch.equal(got["blk.0.w"], full["blk.0.w"]) and torch.equal(got["blk.0.b"], full["blk.0.b"])
+    # 2. an artifact set to None inside a materialised entry (no LazyArtifacts method sees this edit)
+    tv, masks, shapes, cfg, bases, comp = fresh()
+    comp["blk.1.w"]["b"]["masked"] = None
+    assert mg._batched_entry("blk.1.w", comp, bases) is None
+    got = sq.merge_all_parameters(comp, bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
+    want = sq.merge_all_parameters(plain_of(comp), bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
+    assert all(_same_bits(got[n], want[n]) for n in shapes)
+    # 3. the noise basis switched off for one parameter, a basis entry replaced for another
+    tv, masks, shapes, cfg, bases, comp = fresh(include_noise=True)
+    bases["blk.1.w"]["noise"] = None
+    bases["emb"]["masked"]["U_high"] = bases["emb"]["masked"]["U_high"] * 2
+    assert mg._batched_entry("blk.1.w", comp, bases) is None and mg._batched_entry("emb", comp, bases) is None
+    got = sq.merge_all_parameters(comp, bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
+    want = sq.merge_all_parameters(plain_of(comp), bases, masks, weights, shapes, cfg, device="cuda", verbose=False)
+    assert all(_same_bits(got[n], want[n]) for n in shapes)
+    diag = sq.compute_all_diagnostics(tv, comp, bases, masks, cfg, device="cuda")      # and the diagnostics route follows
+    assert set(diag["per_parameter"]) == set(shapes)
+
+
 @pytest.mark.parametrize("with_masks", [False, True])
 def test_batched_diagnostics_match_per_parameter(sq, with_masks):
     """compute_all_diagnostics through svdq_diagnostics (one pass over U and the N deltas per plan; masked parameters:

@@ -177,6 +177,11 @@ def test_masked_from_base_and_consumer_ops_match_the_ctypes_route():
     torch.cuda.synchronize()
     for p, D in enumerate(sizes):
         assert torch.equal(outs[p], buf[offs[p]:offs[p] + D])
+    # a mean buffer that is not the plan's (short, or another dtype) is refused before any kernel reads past its end
+    with pytest.raises((ValueError, RuntimeError), match="mean must be the plan's float32 mean buffer"):
+        torch.ops.svdq.merge(small, basis, mean[:10].contiguous(), sizes, N, 0.9, 0, True, True, 4, 2, w, base)
+    with pytest.raises((ValueError, RuntimeError), match="mean must be the plan's float32 mean buffer"):
+        torch.ops.svdq.merge(small, basis, mean.double(), sizes, N, 0.9, 0, True, True, 4, 2, w, base)
     # plan-level diagnostics of the same buffers (the deltas of the from-base run are fine-tuned minus base)
     d6 = torch.ops.svdq.diagnostics([f - base[p] for p, fs in enumerate(ft) for f in fs], [], small, basis, mean, N,
                                     0.9, 0, True, True, 4, 2, False)
