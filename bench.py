@@ -328,8 +328,9 @@ class Workload:
         # small-artifact exchange: sizes once, buffers preallocated (nothing of this inside the timed region)
         self.gather = None
         if world > 1:
-            self.small_host = torch.empty(plan.small.numel(), dtype=torch.uint8).pin_memory() if on_cpu else None
-            self.gather = shard.RaggedGather(plan.small.numel(), "cpu" if on_cpu else dev)
+            # one code path for RCCL and for the gloo rehearsal: RaggedGather stages through pinned host memory by itself
+            # when the backend cannot take device tensors
+            self.gather = shard.RaggedGather(plan.small.numel(), dev)
         torch.cuda.synchronize()
         self.placement_ms = []
 
@@ -434,11 +435,8 @@ class Workload:
             events[3].record(); plan.coeff_quantize()
             events[4].record()
         if self.gather is not None:
-            if self.on_cpu:       # gloo rehearsal: collectives run on host tensors
-                self.small_host.copy_(plan.small)
-                self.gather.run(self.small_host)
-            else:      # pipelined: the exchange of this step travels while the next step computes (shard.RaggedGather)
-                self.gather.run(plan.small, overlap=True)
+            # pipelined: the exchange of this step travels while the next step computes (shard.RaggedGather)
+            self.gather.run(plan.small, overlap=True)
 
     def timed(self, dist, steps, warmup):
         """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""

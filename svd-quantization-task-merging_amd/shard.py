@@ -42,24 +42,38 @@ class RaggedGather:
     send / receive buffer sets and the caller's stream does not wait for it, so the next step's kernels run while the
     small artifacts of this step travel; a set is waited for only when it comes up for reuse two steps later (a
     stream-level wait, the host never blocks).  ``finish()`` makes the caller's stream wait for everything in flight;
-    ``views()`` then refers to the most recent step."""
+    ``views()`` then refers to the most recent step.
+
+    A backend that cannot take device tensors (``gloo``: the CPU rehearsal of the multi-GPU run) is served from the SAME
+    call: the send / receive sets then live in pinned host memory, ``run`` stages the device buffer into the send slot
+    (one D2H copy + a wait for the caller's stream, the price of the rehearsal backend) and the rest -- alternating sets,
+    asynchronous collective, waits on reuse -- is the code path the RCCL run takes."""
 
     def __init__(self, nbytes_local: int, device, group=None, align: int = 256):
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group)
         self.nbytes = int(nbytes_local)
+        device = torch.device(device)
+        self._staged = device.type == "cuda" and dist.get_backend(group) != "nccl"
+        self._src_device = device
+        if self._staged:
+            device = torch.device("cpu")
         n = torch.tensor([self.nbytes], dtype=torch.int64, device=device)
         sizes = [torch.zeros_like(n) for _ in range(self.world)]
         dist.all_gather(sizes, n, group=group)                       # the only size exchange, at plan time
         self.sizes = [int(s.item()) for s in sizes]
         self.stride = (max(self.sizes) + align - 1) // align * align
-        self._sets = [(torch.zeros(max(self.stride, 1), dtype=torch.uint8, device=device),
-                       torch.empty(max(self.stride, 1) * self.world, dtype=torch.uint8, device=device))]
+        self._sets = [(self._buf(max(self.stride, 1), device, zero=True),
+                       self._buf(max(self.stride, 1) * self.world, device))]
         self._work = [None]
         self._cur = 0
         self._device = device
         self.send, self.recv = self._sets[0]
+
+    def _buf(self, n: int, device, zero: bool = False) -> torch.Tensor:
+        t = (torch.zeros if zero else torch.empty)(n, dtype=torch.uint8, device=device)
+        return t.pin_memory() if self._staged else t
 
     def run(self, buf: torch.Tensor, overlap: bool = False) -> torch.Tensor:
         import torch.distributed as dist
@@ -67,13 +81,16 @@ class RaggedGather:
             raise ValueError(f"buffer has {buf.numel()} bytes, the gather was planned for {self.nbytes}")
         if overlap:
             if len(self._sets) == 1:                                  # the second set, on first use
-                self._sets.append((torch.zeros_like(self._sets[0][0]), torch.empty_like(self._sets[0][1])))
+                self._sets.append((self._buf(self._sets[0][0].numel(), self._device, zero=True),
+                                   self._buf(self._sets[0][1].numel(), self._device)))
                 self._work.append(None)
             self._cur = (self._cur + 1) % 2
             if self._work[self._cur] is not None:                     # its previous collective (two steps ago)
                 self._work[self._cur].wait()
             self.send, self.recv = self._sets[self._cur]
         self.send[:self.nbytes].copy_(buf.view(torch.uint8).reshape(-1), non_blocking=True)
+        if self._staged and buf.is_cuda:
+            torch.cuda.current_stream(buf.device).synchronize()       # the host collective reads the staged bytes
         if overlap:
             self._work[self._cur] = dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=True)
         else:

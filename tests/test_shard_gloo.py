@@ -154,3 +154,36 @@ def test_bench_refuses_more_ranks_than_gpus():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert "needs 4 GPUs" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_takes_the_rccl_code_path():
+    """`SVDQ_DIST_BACKEND=gloo python bench.py --gpus 2` on one card: the same Workload.step as the RCCL run -- LPT shard per
+    rank, `RaggedGather.run(plan.small, overlap=True)` on the DEVICE buffer (the gather stages through pinned host memory
+    by itself for this backend), barrier + max-over-ranks timing -- and the line carries every rank's own stage times and
+    row share, which must be partition_lpt's."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    from svdq_amd import shard, workloads
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["SVDQ_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "ViT-B-32", "--steps", "3",
+                        "--warmup", "1", "--no-cpu", "--no-weak"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3 and d["value"] > 0
+    shapes = workloads.vit_visual_shapes("ViT-B-32")
+    rows = [workloads.numel(shapes[n]) for n in sorted(shapes)]
+    parts = shard.partition_lpt(rows, 2)
+    ranks = sorted(d["per_rank"]["ranks"], key=lambda e: e["rank"])
+    assert [e["rank"] for e in ranks] == [0, 1]
+    for e, part in zip(ranks, parts):
+        assert e["tensors"] == len(part) and e["sum_rows"] == sum(rows[i] for i in part)
+        assert len(e["kernels_ms"]) == 4 and all(x is not None and x > 0 for x in e["kernels_ms"])
+    assert sum(e["sum_rows"] for e in ranks) == sum(rows)
