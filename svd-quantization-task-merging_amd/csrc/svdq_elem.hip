@@ -9,7 +9,9 @@
 //     k_rtvq_apply   residual -> codes_s (1 B/elem), next residual, next stage's partials
 //                                                                            (read 4n, write 5n)
 // Algorithmic bytes n*(4+S); this schedule moves n*(4 + S*9 - 4) because stage s+1's min/max
-// depends on stage s's scale.
+// depends on stage s's scale.  A one-launch form for tensors that fit the register file (x read
+// once, grid-wide meetings between the stages) was built and measured in round 4: 3-8x SLOWER -- a meeting of 10^3
+// workgroups across eight XCDs costs 15-80 us against ~2 us for a kernel boundary (profiles/r04_rtvq_one_launch_experiment.txt).
 
 #include "svdq_common.h"
 #include <hip/hip_fp16.h>
