@@ -387,6 +387,14 @@ class Workload:
         self._keep_comb = comb
         self.rows_dev = ct
 
+    def consumer_tables(self):
+        """What the masked batched consumers walk the source rows with (svdq_merge_masked / svdq_diagnostics_masked): the
+        combined-mask table and one source start per work unit.  The walk-mode compression has built both; after an
+        index-list compression (N > 16, --masks-index) the starts come from the same tile scan, once."""
+        if self.ustart is None:
+            self.mtab = torch.tensor([c.data_ptr() for c in self._keep_comb], dtype=torch.int64).to(self.dev)
+            self.ustart = self.mset.unit_starts(self.plan, self.rows_dev, mask_table=self.mtab)
+
     @property
     def plain(self):
         return self.mset is None and self.fb is None
@@ -483,9 +491,10 @@ def merge_leg(wl, args, dev):
     lib = wl.lib
     masked = args.masks != "none"
     if masked:
-        if not wl.walk:
-            sys.exit("bench.py --merge with masks: the mask-walk mode (N <= 16, no --masks-index / --masks-compact)")
+        if args.masks_compact:
+            sys.exit("bench.py --merge with masks: not with --masks-compact (the plan must see the source tensors)")
         wl.step()      # vote + scan + unit starts + the masked compression: leaves the mask table and the unit starts
+        wl.consumer_tables()
     else:
         plan.run(wl.table)
     torch.cuda.synchronize()
@@ -568,9 +577,11 @@ def diagnostics_leg(wl, args, dev):
     (k_one_hot + k_merge_coeff + k_diag / k_diag_walk + k_diag_finish); returns the JSON fields."""
     plan, N = wl.plan, args.tasks
     masked = args.masks != "none"
-    if masked and not wl.walk:
-        sys.exit("bench.py --diagnostics with masks: the mask-walk mode (N <= 16, no --masks-index / --masks-compact)")
+    if masked and args.masks_compact:
+        sys.exit("bench.py --diagnostics with masks: not with --masks-compact (the plan must see the source tensors)")
     wl.step()
+    if masked:
+        wl.consumer_tables()
     torch.cuda.synchronize()
 
     def step():

@@ -466,6 +466,54 @@ def test_edited_dictionaries_leave_the_batched_route(sq):
     assert set(diag["per_parameter"]) == set(shapes)
 
 
+@pytest.mark.parametrize("n_tasks,fp16,inverted,n_sets", [(8, True, False, 1), (12, False, True, 2), (20, True, False, 2),
+                                                          (20, False, True, 1), (32, True, False, 4)])
+def test_plan_merge_masked_at_every_block_size(sq, n_tasks, fp16, inverted, n_sets):
+    """svdq_merge_masked (k_merge_expand: 256-row chunks up to 16 tasks, 128-row chunks above -- round 3 stopped at 16) against
+    merging in the compacted row space (svdq_merge) and torch's own boolean assignment: bit for bit, + base, both
+    polarities, sparse and dense masks, ragged ends, several sets."""
+    from oracle import svd_hybrid_oracle as orc
+    from svdq_amd.mask_loader import MaskSet
+    from svdq_amd.pipeline import CompressPlan
+    dev = torch.device("cuda", 0)
+    sizes = [9000, 300, 4096 * 3 + 5, 8192 + 300, 61]
+    dens = [0.9, 0.5, 0.97, 0.15, 0.4]
+    gen = torch.Generator().manual_seed(200 + n_tasks)
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, n_tasks, 700 + i, rank=3)] for i, D in enumerate(sizes)]
+    masks = [(torch.rand(D, generator=gen) < q) for D, q in zip(sizes, dens)]
+    sel = [(~m if inverted else m).to(dev) for m in masks]
+    ms = MaskSet(sizes, dev)
+    ct, cf = ms.count_scan([m.to(dev) for m in masks])
+    comb = ms._s["mb"]
+    rows_dev = cf if inverted else ct
+    plan = CompressPlan(sizes, n_tasks, energy_threshold=0.9, max_rank=None, center=True, fp16=fp16, low_bits=4,
+                        rtvq_stages=2, device=dev)
+    mtab = torch.tensor([c.data_ptr() for c in comb], dtype=torch.int64).to(dev)
+    us = ms.unit_starts(plan, rows_dev, entry_map=[(q, inverted) for q in range(len(sizes))])
+    comp = [[torch.cat([v[s_], torch.zeros(D - int(s_.sum()), device=dev)]) for v in vs] for vs, s_, D in zip(vecs, sel, sizes)]
+    plan.run(plan.pointer_table(comp), rows_dev)
+    sm = plan.fetch_small()
+    w = torch.full((n_sets, n_tasks), -1.0)
+    for t in range(n_tasks):
+        w[t % n_sets, t] = 1.0 / len([u for u in range(n_tasks) if u % n_sets == t % n_sets])
+    w = w.to(dev)
+    share = torch.softmax(torch.arange(n_sets, dtype=torch.float32), 0).to(dev) if n_sets > 1 else None
+    base = [torch.randn(D, generator=gen).to(dev) for D in sizes]
+    btab = torch.tensor([b.data_ptr() for b in base], dtype=torch.int64).to(dev)
+    full = [torch.full((D,), float("nan"), device=dev) for D in sizes]
+    otab = torch.tensor([f.data_ptr() for f in full], dtype=torch.int64).to(dev)
+    plan.merge_masked(w, mtab, us, rows_dev, otab, set_share=share, fill=torch.ones(len(sizes), dtype=torch.int32, device=dev),
+                      base_table=btab)
+    cbuf, coffs, ctab = plan.new_merged_outputs()
+    plan.merge(w, set_share=share, rows_dev=rows_dev, out_table=ctab)
+    torch.cuda.synchronize()
+    for p, D in enumerate(sizes):
+        want = torch.zeros(D, device=dev)
+        want[sel[p]] = cbuf[coffs[p]:coffs[p] + int(sm.rows[p])]
+        assert _same_bits(full[p], base[p] + want), (p, D)
+    plan.close()
+
+
 @pytest.mark.parametrize("with_masks", [False, True])
 def test_batched_diagnostics_match_per_parameter(sq, with_masks):
     """compute_all_diagnostics through svdq_diagnostics (one pass over U and the N deltas per plan; masked parameters:
