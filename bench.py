@@ -327,7 +327,8 @@ class Workload:
             self._setup_masks()
         # small-artifact exchange: sizes once, buffers preallocated (nothing of this inside the timed region)
         self.gather = None
-        if world > 1:
+        import torch.distributed as _d
+        if world > 1 or (_d.is_available() and _d.is_initialized()):      # (a one-rank world is still a distributed run)
             # one code path for RCCL and for the gloo rehearsal: RaggedGather stages through pinned host memory by itself
             # when the backend cannot take device tensors
             self.gather = shard.RaggedGather(plan.small.numel(), dev)
@@ -653,7 +654,11 @@ def main():
     scaling = args.scaling or ("strong" if world > 1 else "none")      # one rank: nothing is scaled
     dist = None
     backend = os.environ.get("SVDQ_DIST_BACKEND", "nccl")
-    if world > 1:
+    # SVDQ_DIST_SINGLE=1 (with RANK=0 WORLD_SIZE=1 MASTER_* set): run the one-rank world as a DISTRIBUTED job -- process
+    # group over RCCL, planned gather on device buffers, barrier + max-over-ranks timing, per-rank report: every call of the
+    # 8-GPU run on the one GPU a test box has.  The default one-GPU line does not take this path.
+    multi = world > 1 or (bool(os.environ.get("SVDQ_DIST_SINGLE")) and "RANK" in os.environ)
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # rehearsal on a box with fewer GPUs than ranks: SVDQ_DIST_BACKEND=gloo lets several ranks share a
@@ -667,7 +672,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    on_cpu = world > 1 and backend != "nccl"   # gloo: collectives on host tensors
+    on_cpu = multi and backend != "nccl"   # gloo: collectives on host tensors
 
     import svdq_amd  # noqa: F401
     from svdq_amd import workloads, shard
@@ -747,7 +752,7 @@ def main():
 
     # the two extra figures must never cost the main line (every rank takes the same path: the guards are symmetric)
     try:
-        bgather = basis_gather_ms(plan, dist, dev, on_cpu) if world > 1 else None
+        bgather = basis_gather_ms(plan, dist, dev, on_cpu) if multi else None
     except torch.cuda.OutOfMemoryError:
         bgather = None
 

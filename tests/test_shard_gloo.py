@@ -187,3 +187,74 @@ def test_bench_two_rank_rehearsal_takes_the_rccl_code_path():
         assert e["tensors"] == len(part) and e["sum_rows"] == sum(rows[i] for i in part)
         assert len(e["kernels_ms"]) == 4 and all(x is not None and x > 0 for x in e["kernels_ms"])
     assert sum(e["sum_rows"] for e in ranks) == sum(rows)
+
+
+_RCCL_SMOKE = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from svdq_amd import shard
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # exactly bench.py's call
+assert dist.get_backend() == "nccl"
+n = 70001
+rg = shard.RaggedGather(n, dev)
+assert not rg._staged and rg.send.is_cuda                                   # device buffers, no host staging
+side = torch.cuda.Stream()
+for step in range(5):                                                       # the pipelined form, as Workload.step uses it
+    buf = (torch.arange(n, device=dev) + step).to(torch.uint8)
+    rg.run(buf, overlap=True)
+    with torch.cuda.stream(side):                                           # "the next step's kernels" on another stream
+        torch.ones(1 << 20, device=dev).sum()
+rg.finish()
+torch.cuda.synchronize()
+assert torch.equal(rg.views()[0], ((torch.arange(n, device=dev) + 4).to(torch.uint8)))
+G = torch.arange(64, dtype=torch.float64, device=dev).view(8, 8).clone()
+want = G.clone()
+shard.all_reduce_gram(G)
+tt = torch.tensor([1.25], dtype=torch.float64, device=dev)
+dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(G, want) and float(tt.item()) == 1.25
+dist.destroy_process_group()
+print("rccl ok")
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_process_group_single_rank_smoke():
+    """The RCCL side of the multi-GPU path on the one GPU a test box has: a world of ONE rank over backend "nccl" --
+    `init_process_group(device_id=...)`, the planned gather on DEVICE buffers with asynchronous collectives on two
+    alternating sets, the fp64 Gram all-reduce, the max-over-ranks reduction and the barrier bench.py times with.  It
+    cannot show scaling; it does show that every RCCL call the 8-GPU run makes is accepted by this image's RCCL."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SMOKE, ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_world_over_rccl():
+    """bench.py's own `nccl` branch on one GPU (SVDQ_DIST_SINGLE=1: a world of one rank run as a distributed job): RCCL
+    process group with device_id, RaggedGather on the device buffer with overlap, barrier / max-over-ranks timing, the
+    per-rank report and the separately timed basis gather -- the code the driver's multi-GPU run executes."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("SVDQ_DIST_BACKEND", None)
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               SVDQ_DIST_SINGLE="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "ViT-B-32", "--steps", "3", "--warmup", "1",
+                        "--no-cpu"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert len(d["per_rank"]["ranks"]) == 1 and d["per_rank"]["ranks"][0]["tensors"] == 152
+    assert d["basis_gather"] is not None and d["basis_gather"]["ms"] > 0
