@@ -48,9 +48,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
 # profiled HBM bytes per launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this round's
 # binary, tools/r03_pmc_traffic.sh): (model, tasks, masked) -> file
-TRAFFIC_FILES = {("ViT-L-14", 8, False): os.path.join("profiles", "r03_pmc_traffic.json"),
-                 ("ViT-L-14", 20, False): os.path.join("profiles", "r03_n20_pmc_traffic.json"),
-                 ("ViT-B-16", 8, True): os.path.join("profiles", "r03_masked_vitb16_pmc_traffic.json")}
+TRAFFIC_FILES = {("ViT-L-14", 8, False): os.path.join("profiles", "r04_pmc_traffic.json"),
+                 ("ViT-L-14", 20, False): os.path.join("profiles", "r04_n20_pmc_traffic.json"),
+                 ("ViT-B-16", 8, True): os.path.join("profiles", "r04_masked_vitb16_pmc_traffic.json")}
 
 
 def parse():
