@@ -83,8 +83,13 @@ def oracle_case(sq, orc, dev, seed: int, c: int):
             # column i is U_i = Tc v_i / sigma_i formed in fp32: its own error is ~eps32 sigma_0 / sigma_i, and the
             # coefficient (closed form sigma_i v_i + the fp16-rounding correction) differs from the explicit projection
             # on the stored column by that much of |x| (seed 5001 case 805: sigma_30 = 5e-4 sigma_0, 3e-5 |x|)
+            # The model has no ceiling of its own: round 3 had capped it at 1e-3 |x| by hand, which a direction at
+            # 1.9e-6 sigma_0 -- above the 1e-6 null threshold, below the 1e-5 floor under which not even singular values
+            # are compared; its fp32-formed column is only ~97 % the singular vector -- exceeded with 1.75e-3 |x| (seed 4
+            # case 37: D = 31 < N = 32; model: 0.16 |x|).  Capped where the model reaches 1e-2 (sigma_i = 3e-5 sigma_0);
+            # such a direction holds < 1e-9 of the energy and the reconstructions still agree to MSE 3e-10.
             sg = np.maximum(sm.sigma[0, :r].astype(np.float64), 1e-30)
-            tol = float(np.linalg.norm(x32)) * np.minimum(1e-5 + 3e-7 * sg[0] / sg, 1e-3) + 1e-12
+            tol = float(np.linalg.norm(x32)) * np.minimum(1e-5 + 3e-7 * sg[0] / sg, 1e-2) + 1e-12
             if mu32 is not None:      # the rows of T - mean sum to a few ulp(mean), not to 0; the device removes that
                 tol = tol + 2.4e-7 * float(np.linalg.norm(mu32))      # component (1 / sqrt(N) is deflated), a GEMV keeps it
             if np.isfinite(want).all() and not np.all(np.abs(got - want) <= tol):
