@@ -403,15 +403,20 @@ int svdq_recon_error(const void *u_high_dev, const void *u_low_dev, int32_t u_fp
  *   svdq_merge_coeffs: cbar_dev float [P][n_sets][N] = averaged c_high (columns < k) and dequantized c_low (k..r-1).
  *   svdq_merge_reconstruct: one streaming launch over the plan's units,
  *       out[p][d] = sum_s share[s] * (((U_high c_s,high + U_low c_s,low)[d] + mean[d]) * scale[p])  (+ base[p][d])
- *     set_share_dev: NULL (n_sets = 1: no weighting) or float [n_sets] / [P][n_sets], the clusters' shares renormalised
- *     as apply_weights_to_tensors does (weighting.py:332-372), < 0 = set absent; n_sets <= 8.
+ *     set_share_dev: NULL (n_sets = 1: no weighting) or float [n_sets] / [P][n_sets]: the clusters' shares as
+ *     apply_weights_to_tensors leaves them (weighting.py:332-372: shares / shares.sum() over ALL clusters -- in
+ *     merge_with_clustering a cluster none of whose members holds the parameter still contributes its zeros,
+ *     merge.py:297-299,555-626); < 0 = the set does not hold the parameter: skipped, the others are NOT renormalised;
+ *     n_sets <= 8.
  *     scale_dev: NULL or float [P] (noise_shrink of the noise regions, merge.py:284); base_ptrs_dev: NULL or [P] base
  *     tensors (then out = base + delta); out_ptrs_dev [P] fp32 outputs of rows[p] elements (compacted rows for masked
  *     parameters: svdq_mask_expand scatters them).  A parameter's rows are the bits svdq_reconstruct gives.
  *   svdq_merge = both; work_dev: svdq_merge_work_bytes(plan, n_sets).
  *   svdq_diagnostics: out_dev double [P][N][6], the six numbers of svdq_recon_error for every (parameter, task) from
  *     one pass over U and the N deltas (delta_ptrs_dev as for svdq_compress); add_mean = 0 reproduces the reference
- *     (SURVEY Q1).  work_dev: svdq_diagnostics_work_bytes(plan). */
+ *     (SURVEY Q1).  The reconstruction U_high c_high + U_low c_low is formed in fp32 (matrix pipe), the sums in fp64: every
+ *     number is within the fp32 forward-error bound of diagnostics.py:210-212 of the formula evaluated in fp64 on the same
+ *     artifacts (tests/test_hip_diagnostics.py).  work_dev: svdq_diagnostics_work_bytes(plan). */
 int64_t svdq_merge_work_bytes(const svdq_plan *plan, int32_t n_sets);
 int svdq_merge_coeffs(const svdq_plan *plan, const void *small_dev, const float *weights_dev, const int32_t *order_dev,
                       int32_t n_sets, int32_t per_param, float *cbar_dev, void *stream);
