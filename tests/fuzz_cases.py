@@ -9,6 +9,9 @@ modes_case  : gather mode (against compacted copies), minus-base mode (against i
               (against ingest + gather) and the mask walk must reproduce the plain path bit for bit; the masked
               consumers (svdq_merge_masked, svdq_diagnostics_masked) must reproduce merge / diagnostics of the
               compacted copies.
+diag_case   : the diagnostics kernels (svdq_diagnostics, svdq_diagnostics_masked in both polarities, svdq_recon_error)
+              against diagnostics.py:186-215 evaluated in fp64 on the artifacts the kernel read -- random task counts,
+              ragged sizes, fp16 / fp32, centred or not, unit sizes, mask densities, spikes at random rows.
 Each returns a (description, [mismatch messages]) pair; an empty list means the case is within tolerance."""
 import random
 
@@ -299,4 +302,103 @@ def modes_case(sq, dev, seed: int, c: int):
         extra = [wk, w4, wb]
     for pl in [r2, fb, r3, ga, r4, gb] + extra:
         pl.close()
+    return desc, msgs
+
+
+def diag_case(sq, orc, dev, seed: int, c: int):
+    """All six numbers of every (parameter, task) of a random plan against the reference's formula in fp64 on the plan's
+    own artifacts (helpers.diag_check: 2e-6 + the fp32 forward-error bound of the formula), for the plain kernel, the
+    add_mean extension and the masked walk in one polarity."""
+    from helpers import diag_check
+    from svdq_amd.pipeline import CompressPlan
+    from svdq_amd.mask_loader import MaskSet
+    from svdq_amd import diagnostics as dg
+    rnd = random.Random(9000011 * seed + c)
+    g = torch.Generator().manual_seed(131 * seed + c)
+    N = rnd.choice([1, 2, 3, 4, 5, 7, 8, 8, 9, 12, 15, 16, 17, 19, 20, 20, 21, 24, 25, 28, 31, 32])
+    P = rnd.randint(1, 4)
+    sizes = [rnd.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4095, 4096, 4097, 8193,
+                         rnd.randint(1, 40000)]) for _ in range(P)]
+    fp16, center = rnd.random() < 0.7, rnd.random() < 0.5
+    bits, stages = rnd.choice([4, 8]), rnd.choice([1, 2, 3])
+    unit_rows = rnd.choice([0, 0, 1024, 4096])
+    dens = rnd.choice([0.03, 0.3, 0.6, 0.94, 1.0])
+    inverted = rnd.random() < 0.4
+    desc = (f"N={N} sizes={sizes} fp16={fp16} center={center} bits={bits} stages={stages} unit_rows={unit_rows} "
+            f"dens={dens} inverted={inverted}")
+    kw = dict(energy_threshold=rnd.choice([0.5, 0.9, 0.99]), max_rank=rnd.choice([None, 2, 64]), center=center, fp16=fp16,
+              low_bits=bits, rtvq_stages=stages, device=dev, unit_rows=unit_rows)
+    vecs = []
+    for i, D in enumerate(sizes):
+        ds = [d.clone() for d in orc.synthetic_deltas(D, N, 40000 + 97 * seed + 13 * c + i, rank=min(3, N))]
+        for t, d in enumerate(ds):      # a spike somewhere: a dropped or doubled row cannot hide in the sums
+            d[rnd.randrange(D)] += 2.0 + 0.1 * t
+        vecs.append([d.to(dev) for d in ds])
+    msgs = []
+
+    def artifacts(plan, sm, p, t):
+        k, r, rows = int(sm.k[p]), int(sm.r[p]), int(sm.rows[p])
+        Uh, Ul, mean = plan.basis_tensors(p, k, r, rows)
+        ch = torch.from_numpy(sm.c_high[p, t, :k].astype(np.float32))
+        nl = r - k
+        cl = torch.zeros(0)
+        if nl > 0:
+            cl = torch.from_numpy(orc.rtvq_dequantize({"codes": sm.codes[p, t, :, :nl], "scale": sm.scale[p, t],
+                                                       "zero_point": sm.zero_point[p, t]}).reshape(-1).copy())
+        return Uh.cpu(), Ul.cpu(), ch, cl, (mean.cpu() if mean is not None else None)
+
+    def check(tag, plan, sm, res, xs, with_mean=False):
+        for p in range(P):
+            if int(sm.rows[p]) <= 0:
+                continue
+            for t in range(N):
+                Uh, Ul, ch, cl, mean = artifacts(plan, sm, p, t)
+                if not (torch.isfinite(cl).all() and np.isfinite(res[p, t]).all()):
+                    if torch.isfinite(cl).all() and int(sm.r[p]) - int(sm.k[p]) > 2:
+                        msgs.append(f"{tag}: parameter {p} task {t}: non-finite numbers from finite artifacts")
+                        return
+                    continue      # SURVEY F4: the degenerate quantizer's NaN, as in the reference
+                try:
+                    diag_check(dict(zip(orc.DIAG_KEYS, res[p, t])), xs[p][t], Uh, Ul, ch, cl, what=(tag, p, t),
+                               mean=mean if with_mean else None)
+                except AssertionError as e:
+                    msgs.append(str(e)[:300])
+                    return
+
+    plan = CompressPlan(sizes, N, **kw)
+    table = plan.pointer_table(vecs)
+    plan.run(table)
+    sm = plan.fetch_small()
+    xs = [[v.cpu() for v in vs] for vs in vecs]
+    check("k_diag", plan, sm, plan.diagnostics(table).cpu().numpy(), xs)
+    if center and not msgs:
+        check("add_mean", plan, sm, plan.diagnostics(table, add_mean=True).cpu().numpy(), xs, with_mean=True)
+    if not msgs:      # the per-call kernel on one (parameter, task)
+        p, t = rnd.randrange(P), rnd.randrange(N)
+        Uh, Ul, ch, cl, _ = artifacts(plan, sm, p, t)
+        if torch.isfinite(cl).all():
+            got = dg._fused_error(vecs[p][t], Uh.to(dev), Ul.to(dev), ch, cl, dev)
+            if all(np.isfinite(v) for v in got.values()):
+                try:
+                    diag_check(got, xs[p][t], Uh, Ul, ch, cl, what=("recon_error", p, t))
+                except AssertionError as e:
+                    msgs.append(str(e)[:300])
+    plan.close()
+    if not msgs:      # the masked walk: compress compacted copies declared at the full size, diagnose through the mask
+        masks = [(torch.rand(D, generator=g) < dens) for D in sizes]
+        sel = [(~m if inverted else m) for m in masks]
+        ms = MaskSet(sizes, dev)
+        ct, cf = ms.count_scan([m.to(dev) for m in masks])
+        rows_dev = cf if inverted else ct
+        pm = CompressPlan(sizes, N, **dict(kw, center=False))
+        mtab = torch.tensor([x.data_ptr() for x in ms._s["mb"]], dtype=torch.int64).to(dev)
+        us = ms.unit_starts(pm, rows_dev, entry_map=[(q, inverted) for q in range(P)])
+        comp = [[torch.cat([v[s_.to(dev)], torch.zeros(D - int(s_.sum()), device=dev)]) for v in vs]
+                for vs, s_, D in zip(vecs, sel, sizes)]
+        pm.run(pm.pointer_table(comp), rows_dev)
+        smm = pm.fetch_small()
+        res = pm.diagnostics_masked(table, mtab, us, rows_dev).cpu().numpy()
+        check("walk", pm, smm, res, [[v.cpu()[s_] for v in vs] for vs, s_ in zip(vecs, sel)])
+        pm.close()
+        ms.close()
     return desc, msgs
