@@ -12,6 +12,8 @@ modes_case  : gather mode (against compacted copies), minus-base mode (against i
 diag_case   : the diagnostics kernels (svdq_diagnostics, svdq_diagnostics_masked in both polarities, svdq_recon_error)
               against diagnostics.py:186-215 evaluated in fp64 on the artifacts the kernel read -- random task counts,
               ragged sizes, fp16 / fp32, centred or not, unit sizes, mask densities, spikes at random rows.
+merge_case  : the plan-level merge (svdq_merge: coefficient averaging + streaming reconstruction, sets / shares / scale /
+              + base) against merge.py:61-194, 429-552 evaluated in fp64 on the plan's own artifacts, element by element.
 Each returns a (description, [mismatch messages]) pair; an empty list means the case is within tolerance."""
 import random
 
@@ -401,4 +403,91 @@ def diag_case(sq, orc, dev, seed: int, c: int):
         check("walk", pm, smm, res, [[v.cpu()[s_] for v in vs] for vs, s_ in zip(vecs, sel)])
         pm.close()
         ms.close()
+    return desc, msgs
+
+
+def merge_case(sq, orc, dev, seed: int, c: int):
+    """out = base + sum_s share_s * ((U_high cbar_s,high + U_low cbar_s,low + mean) * scale), cbar_s = sum_t w_st c_t over the
+    present tasks in sorted order (merge.py:61-194; apply_weights_to_tensors; apply_merged_deltas) -- in fp64 from the
+    plan's own basis, fp16 c_high and oracle-dequantized c_low, against svdq_merge element by element.  Tolerance per
+    element: (r + n_sets + 6) 2^-24 times the sum of the magnitudes that enter it (every fp32 rounding of the kernel's
+    chain is relative to a partial sum bounded by that), which is what an fp32 evaluation is entitled to."""
+    from svdq_amd.pipeline import CompressPlan
+    rnd = random.Random(6000011 * seed + c)
+    g = torch.Generator().manual_seed(151 * seed + c)
+    N = rnd.choice([1, 2, 3, 5, 8, 8, 9, 12, 16, 17, 20, 24, 32])
+    P = rnd.randint(1, 4)
+    sizes = [rnd.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4097, rnd.randint(1, 30000)]) for _ in range(P)]
+    fp16, center = rnd.random() < 0.7, rnd.random() < 0.7
+    bits, stages = rnd.choice([4, 8]), rnd.choice([1, 2])
+    n_sets = rnd.choice([1, 1, 2, 3, 4, 8]) if N >= 2 else 1
+    with_base, with_scale = rnd.random() < 0.6, rnd.random() < 0.4
+    desc = f"N={N} sizes={sizes} fp16={fp16} center={center} bits={bits} stages={stages} sets={n_sets} base={with_base}"
+    plan = CompressPlan(sizes, N, energy_threshold=rnd.choice([0.5, 0.9, 0.99]), max_rank=rnd.choice([None, 2, 64]),
+                        center=center, fp16=fp16, low_bits=bits, rtvq_stages=stages, device=dev,
+                        unit_rows=rnd.choice([0, 1024, 4096]))
+    vecs = [[d.to(dev) for d in orc.synthetic_deltas(D, N, 70000 + 89 * seed + 17 * c + i, rank=min(3, N))]
+            for i, D in enumerate(sizes)]
+    plan.run(plan.pointer_table(vecs))
+    sm = plan.fetch_small()
+    # weights [P, S, N]: every task in exactly one set (or absent), renormalised inside the set like merge.py:123-124
+    w = np.full((P, n_sets, N), -1.0, dtype=np.float32)
+    for p in range(P):
+        for t in range(N):
+            if rnd.random() < 0.9 or t == 0:
+                w[p, rnd.randrange(n_sets), t] = np.float32(0.05 + rnd.random())
+        for s_ in range(n_sets):
+            on = w[p, s_] >= 0
+            if on.any():
+                w[p, s_, on] = (w[p, s_, on] / w[p, s_, on].sum(dtype=np.float32)).astype(np.float32)
+    share = None
+    if n_sets > 1:
+        raw = torch.softmax(torch.rand(n_sets, generator=g), 0).numpy().astype(np.float32)
+        share = np.where((w >= 0).any(axis=2), raw[None, :], np.float32(-1.0)).astype(np.float32)      # [P, S]
+    scale = (0.25 + torch.rand(P, generator=g)).numpy().astype(np.float32) if with_scale else None
+    base = [torch.randn(D, generator=g) for D in sizes] if with_base else None
+    buf, offs, otab = plan.new_merged_outputs()
+    bd = [b.to(dev) for b in base] if base is not None else None
+    plan.merge(torch.from_numpy(w).to(dev), set_share=torch.from_numpy(share).to(dev) if share is not None else None,
+               scale=torch.from_numpy(scale).to(dev) if scale is not None else None,
+               base_table=(torch.tensor([b.data_ptr() for b in bd], dtype=torch.int64).to(dev) if bd is not None else None),
+               out_table=otab)
+    torch.cuda.synchronize()
+    msgs = []
+    for p, D in enumerate(sizes):
+        k, r = int(sm.k[p]), int(sm.r[p])
+        Uh, Ul, mean = plan.basis_tensors(p, k, r, D)
+        U = torch.cat([Uh, Ul], dim=1).double().cpu()
+        cs = []
+        for t in range(N):
+            ch = sm.c_high[p, t, :k].astype(np.float64)
+            cl = orc.rtvq_dequantize({"codes": sm.codes[p, t, :, :r - k], "scale": sm.scale[p, t],
+                                      "zero_point": sm.zero_point[p, t]}).reshape(-1).astype(np.float64) if r > k else np.zeros(0)
+            cs.append(np.concatenate([ch, cl]))
+        cs = np.stack(cs)                                            # [N, r]
+        if not np.isfinite(cs).all():
+            continue                                                 # SURVEY F4: the degenerate quantizer's NaN
+        mu = mean.flatten().double().cpu().numpy() if mean is not None else np.zeros(D)
+        sc = float(scale[p]) if scale is not None else 1.0
+        want, mag = np.zeros(D), np.zeros(D)
+        Ua = U.numpy()
+        for s_ in range(n_sets):
+            on = w[p, s_] >= 0
+            if not on.any():
+                continue
+            cbar = (w[p, s_, on].astype(np.float64)[:, None] * cs[on]).sum(0)
+            cabs = (w[p, s_, on].astype(np.float64)[:, None] * np.abs(cs[on])).sum(0)
+            sh = float(share[p, s_]) if share is not None else 1.0
+            want += sh * (Ua @ cbar + mu) * sc
+            mag += abs(sh) * (np.abs(Ua) @ cabs + np.abs(mu)) * abs(sc)
+        if base is not None:
+            want += base[p].double().numpy()
+            mag += np.abs(base[p].double().numpy())
+        got = buf[offs[p]:offs[p] + D].double().cpu().numpy()
+        tol = (r + n_sets + 6) * 2.0 ** -24 * mag + 1e-30
+        if not np.all(np.abs(got - want) <= tol):
+            i = int(np.argmax(np.abs(got - want) / tol))
+            msgs.append(f"merge: parameter {p} row {i}: {got[i]} vs {want[i]} (tol {tol[i]:.2e})")
+            break
+    plan.close()
     return desc, msgs
