@@ -507,7 +507,7 @@ struct DiagPart {
 //             KSH g + s (KSH = ceil(k / 4) steps), low part: column KSL g + (s - KSH): a lane's columns of a part are
 //             consecutive elements of its row, each step one ds_read at a per-step address that advances by a constant
 //             per tile.  Slots past a part's columns carry C = 0 (their U operand is a finite staged value).
-//   N <= 8  : PACK2 -- two 16-row sets share one tile: K slots 0..7 carry set A's columns, 8..15 set B's; result columns
+//   N <= 8  : SETS = 2 (N <= 4: SETS = 4) -- several 16-row sets share one tile.  SETS = 2: K slots 0..7 carry set A's columns, 8..15 set B's; result columns
 //             0..7 are the tasks for set A's rows, 8..15 the same tasks for set B's (C is zero in the off-diagonal
 //             blocks), so no result register is idle.
 //   N > 16  : two task tiles per row tile (the A operand is shared).
@@ -525,12 +525,12 @@ __device__ __forceinline__ float lds_u(const uint8_t *base, int byte_off, float)
     return *reinterpret_cast<const float *>(base + byte_off);
 }
 
-template <int NTP, int RPL_, bool PACK2> struct DiagGeom {
-    static constexpr int RPL = RPL_;                     // rows per lane and block (4 with PACK2)
+template <int NTP, int RPL_, int SETS> struct DiagGeom {
+    static constexpr int RPL = RPL_;                     // rows per lane and block (4 when row sets are packed)
     static constexpr int RB = 64 * RPL;                  // rows per block
     static constexpr int TT = NTP > 16 ? 2 : 1;          // 16-task tiles
-    static constexpr int TROWS = PACK2 ? 32 : 16;        // rows per MFMA tile
-    static constexpr int KMAX = PACK2 ? 4 : NTP / 4 + 1; // K steps of 4 slots
+    static constexpr int TROWS = 16 * SETS;              // rows per MFMA tile
+    static constexpr int KMAX = SETS > 1 ? 4 : NTP / 4 + 1; // K steps of 4 slots
 };
 __host__ __device__ constexpr int diag_xs(int rb, bool walk) { return rb + 4 + (walk ? 64 : 0); }   // X strip stride (floats)
 
@@ -543,7 +543,7 @@ template <bool B> struct DiagBool { static constexpr bool value = B; };
 #else
 #define SVDQ_DIAG_ATTR
 #endif
-template <int NTP, int RPL_, bool PACK2, bool FULL, bool U16, bool WALK>
+template <int NTP, int RPL_, int SETS, bool FULL, bool U16, bool WALK>
 __global__ __launch_bounds__(64) SVDQ_DIAG_ATTR void k_diag(const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
                                              const float *const *__restrict__ ptrs,
                                              const uint8_t *const *__restrict__ mask_ptrs,
@@ -553,8 +553,11 @@ __global__ __launch_bounds__(64) SVDQ_DIAG_ATTR void k_diag(const SvdqParam *__r
                                              int add_mean, const float *__restrict__ ctask /* [P][N][N] */,
                                              DiagPart *__restrict__ part /* [n_units][N] */) {
     using T = typename UElem<U16>::type;
-    using G = DiagGeom<NTP, RPL_, PACK2>;
-    static_assert(!PACK2 || RPL_ == 4, "PACK2 tiles are 32 rows of a 256-row block");
+    using G = DiagGeom<NTP, RPL_, SETS>;
+    static_assert(SETS == 1 || (RPL_ == 4 && NTP * SETS <= 16), "packed row sets: 16 / SETS tasks each, 256-row blocks");
+    constexpr bool PACK = SETS > 1;
+    constexpr int TPS = 16 / SETS;      // tasks (and K slots) per row set
+    constexpr int SPS = 4 / SETS;       // K steps per row set
     constexpr int ES = U16 ? 2 : 4;
     constexpr int RPL = G::RPL, RB = G::RB, TT = G::TT, TROWS = G::TROWS, KMAX = G::KMAX;
     constexpr int XSD = diag_xs(RB, WALK);
@@ -572,10 +575,10 @@ __global__ __launch_bounds__(64) SVDQ_DIAG_ATTR void k_diag(const SvdqParam *__r
     int64_t cpos = ud.row0;
     int64_t cend = ud.row0 + ud.nrows;
     if (cend > D) cend = D;
-    // the task whose column this lane holds in each task tile (PACK2: both row sets carry tasks 0..7)
+    // the task whose column this lane holds in each task tile (packed: every row set carries tasks 0 .. TPS - 1)
     int task[TT];
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) task[tt] = PACK2 ? (col & 7) : col + 16 * tt;
+    for (int tt = 0; tt < TT; ++tt) task[tt] = PACK ? (col % TPS) : col + 16 * tt;
     double se[TT], sx[TT], sr[TT], sa[TT];
     float mx[TT];
 #pragma unroll
@@ -585,12 +588,12 @@ __global__ __launch_bounds__(64) SVDQ_DIAG_ATTR void k_diag(const SvdqParam *__r
     }
     if (cpos < cend) {      // wave-uniform
         const int k = k_in[p], r = r_in[p], nl = r - k;
-        const int KSH = PACK2 ? 0 : (k + 3) >> 2, KSL = PACK2 ? 0 : (nl + 3) >> 2;
-        const int KT = PACK2 ? 4 : KSH + KSL;
+        const int KSH = PACK ? 0 : (k + 3) >> 2, KSL = PACK ? 0 : (nl + 3) >> 2;
+        const int KT = PACK ? 4 : KSH + KSL;
         // basis column of K slot (step s, this lane's group), -1 = the slot is idle
         auto slot_col = [&](int s) -> int {
-            if constexpr (PACK2) {
-                const int c = 2 * g + (s & 1);
+            if constexpr (PACK) {      // step s belongs to row set s / SPS; the lane group's columns are consecutive
+                const int c = SPS * g + (s % SPS);
                 return c < r ? c : -1;
             } else {
                 if (s < KSH) {
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(64) SVDQ_DIAG_ATTR void k_diag(const SvdqParam *__r
             for (int s = 0; s < KMAX; ++s) {
                 const int c = slot_col(s);
                 bool on = c >= 0 && task[tt] < n;
-                if constexpr (PACK2) on = on && ((s >> 1) == (col >> 3));      // set A's slots feed columns 0..7 only
+                if constexpr (PACK) on = on && ((s / SPS) == (col / TPS));      // a set's slots feed its own result columns only
                 creg[tt][s] = on ? ctask[(size_t)p * n * n + (size_t)task[tt] * n + c] : 0.f;
             }
         const uint8_t *slab = basis + pd.slab_off;
@@ -761,7 +764,7 @@ __global__ __launch_bounds__(64) SVDQ_DIAG_ATTR void k_diag(const SvdqParam *__r
                     for (int s = 0; s < KMAX; ++s) {
                         int c = slot_col(s);
                         if (c < 0) c = 0;                                   // an idle slot reads a staged value (times C = 0)
-                        const int row = col + ((PACK2 && s >= 2) ? 16 : 0);
+                        const int row = col + (PACK ? 16 * (s / SPS) : 0);
                         const bool hi = c < k;
                         const int w = hi ? k : nl;
                         ua[s] = (hi ? baseH : baseL) + (row * w + (hi ? c : c - k)) * ES;
@@ -792,13 +795,13 @@ __global__ __launch_bounds__(64) SVDQ_DIAG_ATTR void k_diag(const SvdqParam *__r
                         a[s] = a_in[s];
                         if constexpr (MASKED) {
                             // the block's last tile: rows past its count were never staged; whatever sits there must not
-                            // reach the matrix pipe -- a NaN times a zero coefficient is a NaN in a VALID row's sum (PACK2:
+                            // reach the matrix pipe -- a NaN times a zero coefficient is a NaN in a VALID row's sum (packed:
                             // set B's rows feed set A's result columns through the zero blocks of C)
-                            const int arow = ti * TROWS + col + ((PACK2 && s >= 2) ? 16 : 0);
+                            const int arow = ti * TROWS + col + (PACK ? 16 * (s / SPS) : 0);
                             a[s] = arow < count ? a[s] : 0.f;
                         }
                     }
-                    const int rb = ti * TROWS + (PACK2 ? 16 * (col >> 3) : 0) + 4 * g;      // the lane's four rows
+                    const int rb = ti * TROWS + (PACK ? 16 * (col / TPS) : 0) + 4 * g;      // the lane's four rows
                     f32x4 x[TT], acc[TT];
 #pragma unroll
                     for (int tt = 0; tt < TT; ++tt) {
@@ -877,7 +880,7 @@ __global__ __launch_bounds__(64) SVDQ_DIAG_ATTR void k_diag(const SvdqParam *__r
         double qa = se[tt], qb = sx[tt], qc = sr[tt], qd = sa[tt];
         float q = mx[tt];
 #pragma unroll
-        for (int off = 32; off >= (PACK2 ? 8 : 16); off >>= 1) {
+        for (int off = 32; off >= (PACK ? TPS : 16); off >>= 1) {
             qa += __shfl_xor(qa, off);
             qb += __shfl_xor(qb, off);
             qc += __shfl_xor(qc, off);
@@ -885,7 +888,7 @@ __global__ __launch_bounds__(64) SVDQ_DIAG_ATTR void k_diag(const SvdqParam *__r
             const float o = __shfl_xor(q, off);
             q = (q != q) ? q : ((o != o) ? o : (o > q ? o : q));
         }
-        if (lane < (PACK2 ? 8 : 16) && task[tt] < n) {
+        if (lane < (PACK ? TPS : 16) && task[tt] < n) {
             DiagPart &dst = part[(size_t)blockIdx.x * n + task[tt]];
             dst.se = qa;
             dst.sx = qb;
@@ -1093,18 +1096,18 @@ __global__ void k_one_hot(int n, float *w) {
 #ifndef SVDQ_DIAG_RPL_MID
 #define SVDQ_DIAG_RPL_MID 2      // rows per lane and block of the 9..24-task variants (A/B builds)
 #endif
-template <int NTP, int RPL, bool PACK2, bool FULL>
+template <int NTP, int RPL, int SETS, bool FULL>
 static void launch_diag(const svdq_plan *pl, const void *ptrs, const void *mask_ptrs, const int64_t *unit_start,
                         const int64_t *rows_dev, const int32_t *kk, const int32_t *rr, const uint8_t *basis,
                         const float *mean, int add_mean, const float *ctask, DiagPart *part, hipStream_t st) {
     auto pp = reinterpret_cast<const float *const *>(ptrs);
     auto mp = reinterpret_cast<const uint8_t *const *>(mask_ptrs);
-    using G = DiagGeom<NTP, RPL, PACK2>;
+    using G = DiagGeom<NTP, RPL, SETS>;
     const int n = pl->n_tasks, es = pl->cfg.fp16 ? 2 : 4;
     const size_t lds = (size_t)svdq_align_up((int64_t)G::RB * n * es + 48, 16) +
                        (size_t)(NTP + 1) * diag_xs(G::RB, mp != nullptr) * 4;
 #define SVDQ_DIAG_LAUNCH(F16, WALK_)                                                                                   \
-    hipLaunchKernelGGL((k_diag<NTP, RPL, PACK2, FULL, F16, WALK_>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params, \
+    hipLaunchKernelGGL((k_diag<NTP, RPL, SETS, FULL, F16, WALK_>), dim3(pl->n_units), dim3(64), lds, st, pl->d_params, \
                        pl->d_units, pp, mp, unit_start, rows_dev, n, kk, rr, basis, mean, add_mean, ctask, part)
     if (pl->cfg.fp16) {
         if (mp) SVDQ_DIAG_LAUNCH(true, true); else SVDQ_DIAG_LAUNCH(true, false);
@@ -1143,13 +1146,14 @@ static int run_diagnostics(const char *who, const svdq_plan *pl, const void *del
         if (n == NTP_) launch_diag<NTP_, RPL_, PACK_, true>(SVDQ_DIAG_ARGS);                                            \
         else launch_diag<NTP_, RPL_, PACK_, false>(SVDQ_DIAG_ARGS);                                                     \
     } while (0)
-    if (n <= 8) SVDQ_DIAG_PICK(8, 4, true);
-    else if (n <= 12) SVDQ_DIAG_PICK(12, SVDQ_DIAG_RPL_MID, false);
-    else if (n <= 16) SVDQ_DIAG_PICK(16, SVDQ_DIAG_RPL_MID, false);
-    else if (n <= 20) SVDQ_DIAG_PICK(20, SVDQ_DIAG_RPL_MID, false);
-    else if (n <= 24) SVDQ_DIAG_PICK(24, SVDQ_DIAG_RPL_MID, false);
-    else if (n <= 28) SVDQ_DIAG_PICK(28, 1, false);
-    else if (n <= 32) SVDQ_DIAG_PICK(32, 1, false);
+    if (n <= 4) SVDQ_DIAG_PICK(4, 4, 4);
+    else if (n <= 8) SVDQ_DIAG_PICK(8, 4, 2);
+    else if (n <= 12) SVDQ_DIAG_PICK(12, SVDQ_DIAG_RPL_MID, 1);
+    else if (n <= 16) SVDQ_DIAG_PICK(16, SVDQ_DIAG_RPL_MID, 1);
+    else if (n <= 20) SVDQ_DIAG_PICK(20, SVDQ_DIAG_RPL_MID, 1);
+    else if (n <= 24) SVDQ_DIAG_PICK(24, SVDQ_DIAG_RPL_MID, 1);
+    else if (n <= 28) SVDQ_DIAG_PICK(28, 1, 1);
+    else if (n <= 32) SVDQ_DIAG_PICK(32, 1, 1);
     else {
         svdq_set_error("%s: unsupported task count %d", who, (int)n);
         return SVDQ_EUNSUPPORTED;
