@@ -72,7 +72,7 @@ def _spiked(vecs, sizes, gen):
     return vecs
 
 
-@pytest.mark.parametrize("n_tasks,fp16,center", [(3, True, True), (8, True, True), (8, False, False), (12, True, False),
+@pytest.mark.parametrize("n_tasks,fp16,center", [(1, True, False), (2, False, True), (3, True, True), (4, True, False), (5, False, True), (8, True, True), (8, False, False), (12, True, False),
                                                  (16, False, True), (20, True, False), (20, False, True),
                                                  (28, True, True), (32, False, False)])
 def test_plan_diagnostics_vs_fp64_oracle(sq, n_tasks, fp16, center):
@@ -109,7 +109,7 @@ def test_plan_diagnostics_vs_fp64_oracle(sq, n_tasks, fp16, center):
     plan.close()
 
 
-@pytest.mark.parametrize("n_tasks,fp16,inverted", [(4, True, False), (8, True, True), (8, False, False), (16, True, False),
+@pytest.mark.parametrize("n_tasks,fp16,inverted", [(2, True, True), (4, True, False), (8, True, True), (8, False, False), (16, True, False),
                                                    (20, True, False), (20, False, True), (32, True, False)])
 def test_masked_plan_diagnostics_vs_fp64_oracle(sq, n_tasks, fp16, inverted):
     """svdq_diagnostics_masked (the walk form: apply_mask_to_tensor, mask_loader.py:651-679, inside the pass) against the
