@@ -90,3 +90,23 @@ table = td
 G = torch.empty((N, N), dtype=torch.float64, device=dev)
 ms = timed(lambda: lib.svdq_task_gram(plan._h, _ptr(table), c_void_p(0), _ptr(plan.workspace), _ptr(G), _stream_ptr()))
 emit("svdq_task_gram", ms, total * N * 4, tensors=len(rows), tasks=N, launches=3)
+
+# ---- the same at 20 tasks (BASELINE config #5: cluster weighting needs the Gram of the concatenated task vectors)
+del codes, deltas, base, batch, plan
+torch.cuda.empty_cache()
+N20 = 20
+bufs20, views20 = workloads.synth_task_buffers(rows, N20, seed=3, device=dev)
+plan20 = sq.CompressPlan(rows, N20, center=False, device=dev, gram_only=True)
+t20 = plan20.pointer_table(views20)
+G20 = torch.empty((N20, N20), dtype=torch.float64, device=dev)
+ms = timed(lambda: lib.svdq_task_gram(plan20._h, _ptr(t20), c_void_p(0), _ptr(plan20.workspace), _ptr(G20), _stream_ptr()))
+emit("svdq_task_gram", ms, total * N20 * 4, tensors=len(rows), tasks=N20, launches=3)
+import time
+from svdq_amd import clustering
+names20 = [f"t{i:02d}" for i in range(N20)]
+Gh = G20.cpu().numpy()
+for label in ("first call (imports sklearn)", "warm"):
+    t0 = time.perf_counter()
+    lab = clustering.cluster_from_gram(Gh, names20, 2, "kmeans")
+    print(json.dumps({"host": f"clustering.cluster_from_gram(kmeans, k=2) on the 20 x 20 Gram, {label}",
+                      "ms": round(1e3 * (time.perf_counter() - t0), 2)}), flush=True)
