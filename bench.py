@@ -103,6 +103,9 @@ def parse():
                     help="time the plan-level diagnostics (all N error tuples of every parameter from one pass over U and "
                          "the N deltas: svdq_diagnostics / svdq_diagnostics_masked) instead of the compression")
     ap.add_argument("--clusters", type=int, default=1, help="--merge: number of task clusters (sets), 1..8")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="one GPU: compress only rank 0's share of a strong-scaling run over this many ranks (what one "
+                         "GPU of the multi-GPU run does per step; with SVDQ_DIST_SINGLE=1 including the RCCL exchange)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -682,6 +685,10 @@ def main():
     rows_all = [workloads.numel(shapes[n]) for n in names]
     N = args.tasks
     mine = shard.partition_lpt(rows_all, world)[rank] if (world > 1 and scaling == "strong") else list(range(len(names)))
+    if args.shard_of > 1:
+        if world > 1:
+            sys.exit("bench.py --shard-of: a one-GPU rehearsal of one rank's share")
+        mine = shard.partition_lpt(rows_all, args.shard_of)[0]
     rows = [rows_all[i] for i in mine]
 
     wl = Workload(args, rows, dev, 1234 + rank, world, on_cpu)
@@ -803,7 +810,8 @@ def main():
                                             (f" (tune_placement failed: {placement_error})"
                                              if placement_error else "")),
                        "masks": args.masks, "mask_density": mask_density,
-                       "sharding": "none" if world == 1 else (
+                       "sharding": (f"rehearsal: rank 0's LPT share of {args.shard_of} ranks" if args.shard_of > 1 else "none")
+                       if world == 1 else (
                            "one model per rank" if scaling == "weak" else "one model, LPT over parameter tensors")},
             "roofline": {"bound": "hbm", "kernel": "k_basis_project", "achieved": round(bp_gbs, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bp_gbs / HBM_PEAK_GBS, 4),

@@ -454,6 +454,7 @@ UNROLL_N(SVDQ_UNROLL_GRAM_P1)
 #ifndef SVDQ_GRAM64_WAVES16
 #define SVDQ_GRAM64_WAVES16 3
 #endif
+SVDQ_STAMP_DECL(svdq_stamps_gram)
 template <int NTP, int MODE, bool F64, bool FULL>
 __global__ __launch_bounds__(64, (F64 && (MODE == 0 || MODE == 4) && NTP <= 16) ? (NTP <= 8 ? SVDQ_GRAM64_WAVES8 : SVDQ_GRAM64_WAVES16) : 1) void k_gram(const SvdqParam *__restrict__ params,
                                              const SvdqUnit *__restrict__ units,
@@ -465,8 +466,10 @@ __global__ __launch_bounds__(64, (F64 && (MODE == 0 || MODE == 4) && NTP <= 16) 
                                              const void *const *__restrict__ aux2, int order,
                                              const int64_t *__restrict__ ustart) {
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
-    gram_unit<NTP, MODE, F64, FULL>(X, unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, order), params, units, ptrs,
-                                    rows_dev, NT, center, gram_part, aux, only, aux2, ustart);
+    SVDQ_STAMP_BEGIN();
+    const int uidx = unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, order);
+    gram_unit<NTP, MODE, F64, FULL>(X, uidx, params, units, ptrs, rows_dev, NT, center, gram_part, aux, only, aux2, ustart);
+    SVDQ_STAMP_END(svdq_stamps_gram, uidx);
 }
 
 // ------------------------------------------------------------------------------------ launchers
@@ -545,3 +548,9 @@ int svdq_launch_gram(const svdq_plan *pl, const void *ptrs, const int64_t *rows_
     return SVDQ_EUNSUPPORTED;
 }
 
+
+#ifdef SVDQ_UNIT_STAMPS
+extern "C" int svdq_debug_stamps_gram(unsigned long long *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(svdq_stamps_gram), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif

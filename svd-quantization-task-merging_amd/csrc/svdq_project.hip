@@ -410,6 +410,7 @@ UNROLL_N(SVDQ_UNROLL_BP)
     }
 }
 
+SVDQ_STAMP_DECL(svdq_stamps_project)
 template <int NTP, bool OUT16, int MODE, bool FULL>
 __global__ __launch_bounds__(64) void k_basis_project(
     const SvdqParam *__restrict__ params, const SvdqUnit *__restrict__ units,
@@ -420,9 +421,11 @@ __global__ __launch_bounds__(64) void k_basis_project(
     using out_t = typename OutT<OUT16>::type;
     __shared__ __attribute__((aligned(16))) float X[NTP * XS];
     __shared__ __attribute__((aligned(16))) out_t OUT[SVDQ_BLK_ROWS * NTP + 16];  // +16: dump slot for idle lanes
+    SVDQ_STAMP_BEGIN();
     const int uidx = unit0 + unit_of_block((int)blockIdx.x, (int)gridDim.x, reverse);
     bp_unit<NTP, OUT16, MODE, FULL>(X, OUT, uidx, params, units, ptrs, rows_dev, NT, center, Wtab, k_dev, r_dev, basis,
                                     meanbuf, cpart, aux, aux2, ustart);
+    SVDQ_STAMP_END(svdq_stamps_project, uidx);
 }
 
 // ------------------------------------------------------------------------------------ N > 16: two waves
@@ -1161,3 +1164,9 @@ int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64
     return SVDQ_EUNSUPPORTED;
 }
 
+
+#ifdef SVDQ_UNIT_STAMPS
+extern "C" int svdq_debug_stamps_project(unsigned long long *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(svdq_stamps_project), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -27,6 +27,28 @@
 // Accumulation: fp32 inside a block (64 MFMA k-steps), fp64 across blocks and units.
 
 #pragma once
+// SVDQ_UNIT_STAMPS (diagnostic builds only, tools/unit_timeline.py): every work unit of the two streaming passes records
+// when its wavefront started and ended (s_memrealtime, 100 MHz) and on which XCD it ran, so that the ramp-up, the
+// steady state and the tail of a launch can be drawn.  Nothing is emitted otherwise.
+#ifdef SVDQ_UNIT_STAMPS
+#define SVDQ_STAMP_DECL(name) __device__ unsigned long long *name = nullptr;
+#define SVDQ_STAMP_BEGIN() const unsigned long long stamp_t0_ = wall_clock64()
+#define SVDQ_STAMP_END(name, u)                                                       \
+    do {                                                                              \
+        if (name && (threadIdx.x == 0)) {                                             \
+            unsigned hw = 0;                                                          \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));         \
+            name[3 * (size_t)(u)] = stamp_t0_;                                        \
+            name[3 * (size_t)(u) + 1] = wall_clock64();                               \
+            name[3 * (size_t)(u) + 2] = hw;                                           \
+        }                                                                             \
+    } while (0)
+#else
+#define SVDQ_STAMP_DECL(name)
+#define SVDQ_STAMP_BEGIN()
+#define SVDQ_STAMP_END(name, u)
+#endif
+
 #include "svdq_common.h"
 #include <hip/hip_fp16.h>
 
