@@ -75,6 +75,8 @@ def parse():
                     help="hand the per-task masks over bit-packed (numpy.packbits order, the form TALL_mask files have)")
     ap.add_argument("--masks-compact", action="store_true",
                     help="A/B: materialise compacted copies of the deltas (the pre-gather schedule) instead")
+    ap.add_argument("--masks-walk", action="store_true",
+                    help="masked runs above 16 tasks: the mask walk (one-wave kernels) instead of the index lists")
     ap.add_argument("--masks-index", action="store_true",
                     help="A/B: int32 index lists + gather-mode passes (round 2's schedule; still what sparse masks and "
                          "N > 16 use) instead of the mask walk (source rows + mask byte, compaction in LDS)")
@@ -355,7 +357,9 @@ class Workload:
         self._keep_masks = flat
         self.mset = mset = MaskSet(rows, dev)
         comb, counts = mset.prepare_combine(per_task, args.masks)
-        self.walk = not (args.masks_index or args.masks_compact) and N <= 16
+        # above 16 tasks the walk runs the one-wave pass 2 (one wave per SIMD): the index lists feed the faster two-wave
+        # kernels and stay the default there; --masks-walk forces the walk (measurement)
+        self.walk = not (args.masks_index or args.masks_compact) and (N <= 16 or args.masks_walk)
         self.mtab = self.ustart = None
         if args.masks_packed:
             # one bit stream per task over the concatenated parameters (first element = most significant bit)

@@ -201,8 +201,10 @@ int svdq_compress_gather_from_base(const svdq_plan *plan, const void *finetuned_
  * svdq_maskset_combine_starts; bit 62 set = the unit takes the CLEARED elements, i.e. the noise region), rows_dev[p] the
  * number of selected rows.  Both passes walk the source rows with contiguous loads, read the mask byte beside them and
  * compact the selected rows into the LDS strip: 4 N + 1 bytes per source row and pass against (4 N + 4) per selected row
- * through index lists.  Artifacts are those of svdq_compress on the compacted tensors, bit for bit.  N <= 16 tasks
- * (SVDQ_EUNSUPPORTED above: use svdq_compress_gather). */
+ * through index lists.  Artifacts are those of svdq_compress on the compacted tensors, bit for bit.  Above 16 tasks both
+ * passes run their one-wave kernels (one wavefront per SIMD: measured 20-24 % slower than svdq_compress_gather, whose index
+ * lists feed the two-wave kernels; for N = 17..20 bit-identical to the two-wave kernel, plan flag 8).  The _from_base form
+ * covers N <= 16 (SVDQ_EUNSUPPORTED above: use svdq_compress_gather_from_base). */
 int svdq_compress_masked(const svdq_plan *plan, const void *delta_ptrs, const void *mask_ptrs,
                          const int64_t *unit_start, const int64_t *rows_dev, void *workspace_dev, void *small_dev,
                          void *basis_dev, float *mean_dev, void *stream);

@@ -480,18 +480,14 @@ extern "C" int svdq_compress_gather_from_base(const svdq_plan *pl, const void *f
 // (svdq_maskset_unit_starts / _combine_starts; its bit 62 selects the cleared elements -- the noise region) and
 // rows_dev[p] how many rows parameter p has.  The passes walk the source rows, read the mask beside them and compact
 // the selected rows into the LDS strip on the fly: 4 N + 1 bytes per source row and pass, no index lists, no compacted
-// copies.  Outputs are those of svdq_compress on the compacted tensors, bit for bit.  N <= 16.
+// copies.  Outputs are those of svdq_compress on the compacted tensors, bit for bit.  Above 16 tasks both passes take
+// their one-wave kernels (svdq_project_walk.hip): slower per byte than the two-wave kernels the index-list route runs.
 extern "C" int svdq_compress_masked(const svdq_plan *pl, const void *ptrs, const void *mask_ptrs,
                                     const int64_t *unit_start, const int64_t *rows_dev, void *workspace, void *small,
                                     void *basis, float *mean, void *stream) {
     if (!pl || !mask_ptrs || !unit_start || !rows_dev) {
         svdq_set_error("svdq_compress_masked: plan, mask_ptrs, unit_start and rows_dev are required");
         return SVDQ_EINVAL;
-    }
-    if (pl->ntp > 16) {
-        svdq_set_error("the mask-walk mode covers N <= 16 tasks (got %d): use the index lists (svdq_compress_gather)",
-                       pl->n_tasks);
-        return SVDQ_EUNSUPPORTED;
     }
     if (small)
         HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(small) + pl->small.status_off, 0, sizeof(int32_t),

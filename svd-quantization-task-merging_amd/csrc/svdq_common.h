@@ -73,6 +73,11 @@ int svdq_launch_basis_project(const svdq_plan *pl, const void *ptrs, const int64
                               const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean,
                               double *cpart, int unit0, int nunits, int reverse, const void *idx, const void *base,
                               hipStream_t st, const int64_t *ustart = nullptr);
+// pass 2 of the mask-walk mode for 16 < N <= 32 (svdq_project_walk.hip)
+int svdq_launch_basis_project_walk32(const svdq_plan *pl, const float *const *pp, const int64_t *rows_dev, const float *W,
+                                     const int32_t *k_dev, const int32_t *r_dev, uint8_t *basis, float *mean, double *cpart,
+                                     int unit0, int nunits, int reverse, const void *const *masks, const int64_t *ustart,
+                                     hipStream_t st);
 // refine_out: NULL, or a device table [n_params] that receives 1 where a singular value lies in the band the fp32-product
 // Gram does not resolve (then the caller re-accumulates those parameters in fp64 and calls again with only = that table)
 int svdq_launch_eig(const svdq_plan *pl, const void *ptrs, const int64_t *rows_dev, const double *gram_part, float *W,

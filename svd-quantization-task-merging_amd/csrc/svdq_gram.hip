@@ -507,10 +507,14 @@ static int launch_gram_t(const svdq_plan *pl, const void *ptrs, const int64_t *r
             return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
         }
     }
-    if (mode & 4) {
-        svdq_set_error("the mask-walk mode covers N <= 16 tasks (got %d): use the index lists (svdq_compress_gather)",
-                       pl->n_tasks);
-        return SVDQ_EUNSUPPORTED;
+    if (mode & 4) {      // 16 < N <= 32: the same one-wave kernel walks (pass 2: svdq_project_walk.hip); not from checkpoints
+        if (mode != 4) {
+            svdq_set_error("the mask walk straight from checkpoints covers N <= 16 tasks (got %d): use the index lists "
+                           "(svdq_compress_gather_from_base)", pl->n_tasks);
+            return SVDQ_EUNSUPPORTED;
+        }
+        if (f64) SVDQ_LAUNCH_GRAM_(4, true, false); else SVDQ_LAUNCH_GRAM_(4, false, false);
+        return hipGetLastError() == hipSuccess ? SVDQ_OK : SVDQ_EHIP;
     }
     if (f64) {
         switch (mode) {

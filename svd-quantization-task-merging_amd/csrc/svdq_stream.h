@@ -31,7 +31,7 @@
 // when its wavefront started and ended (s_memrealtime, 100 MHz) and on which XCD it ran, so that the ramp-up, the
 // steady state and the tail of a launch can be drawn.  Nothing is emitted otherwise.
 #ifdef SVDQ_UNIT_STAMPS
-#define SVDQ_STAMP_DECL(name) __device__ unsigned long long *name = nullptr;
+#define SVDQ_STAMP_DECL(name) static __device__ unsigned long long *name = nullptr;
 #define SVDQ_STAMP_BEGIN() const unsigned long long stamp_t0_ = wall_clock64()
 #define SVDQ_STAMP_END(name, u)                                                       \
     do {                                                                              \

@@ -13,7 +13,7 @@
 //   compress(Tensor[] deltas, int n_tasks, float energy, int max_rank, bool center, bool fp16, int bits, int stages)
 //       -> (Tensor small, Tensor basis, Tensor mean)          packed buffers: svdq_plan_small_layout / _basis_layout
 //   compress_masked(Tensor[] deltas, Tensor[] masks, int n_tasks, <settings>) -> (small, basis, mean, Tensor rows)
-//       masks[p] = the combined mask of parameter p; mask walk (svdq_compress_masked), N <= 16
+//       masks[p] = the combined mask of parameter p; mask walk (svdq_compress_masked)
 //   compress_gather(...same...)                                the same through int32 index lists (svdq_compress_gather)
 //   compress_from_base(Tensor[] finetuned, Tensor[] base, int n_tasks, <settings>) -> (small, basis, mean)
 //   mask_combine_indices(Tensor[] masks, int n_masks, str strategy) -> (Tensor[] combined, Tensor[] indices, Tensor counts)
@@ -346,7 +346,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> compress_from_base(at::TensorList
 }
 
 // masked parameters: masks[p] = the combined mask of parameter p (bool / uint8, the parameter's shape).
-// walk = true: svdq_maskset_count_scan + _unit_starts + svdq_compress_masked (no index lists; N <= 16);
+// walk = true: svdq_maskset_count_scan + _unit_starts + svdq_compress_masked (no index lists; above 16 tasks on the one-wave kernels);
 // walk = false: svdq_maskset_indices + svdq_compress_gather.  rows (int64 [P], device) = mask.sum() per parameter.
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> compress_with_masks(at::TensorList deltas, at::TensorList masks,
                                                                                int64_t n_tasks, double energy,

@@ -16,7 +16,9 @@ from . import mask_loader as ml
 
 
 # the mask-walk mode (svdq_compress_masked) serves regions that hold at least this share of their tensors' elements --
-# below it, skipping rows through index lists reads less than walking past them -- and the one-wave kernels (N <= 16)
+# below it, skipping rows through index lists reads less than walking past them -- and the task counts whose default
+# kernels walk at full speed (N <= 16; above, the walk exists but runs the one-wave pass 2, measured 20-24 % behind the
+# index lists that feed the two-wave kernels)
 WALK_MIN_DENSITY = 0.5
 WALK_MAX_TASKS = 16
 

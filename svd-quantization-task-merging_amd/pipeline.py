@@ -247,7 +247,8 @@ class CompressPlan:
         """run() for masked parameters without index lists: ``table`` names the ORIGINAL full-size task tensors,
         ``mask_table`` (device int64 [P]) the combined bool-byte masks, ``unit_start`` the source position of every
         work unit's first row (MaskSet.unit_starts / run_combine_starts), ``rows_dev`` the selected-row counts.
-        Both passes walk the source rows and compact them in LDS (N <= 16)."""
+        Both passes walk the source rows and compact them in LDS (above 16 tasks on the one-wave kernels: ~20 % slower
+        than ``run_gather``, which feeds the two-wave kernels, but no index lists)."""
         nat.check(self.lib.svdq_compress_masked(self._h, _ptr(table), _ptr(mask_table), _ptr(unit_start),
                                                 _ptr(rows_dev), _ptr(self.workspace), _ptr(self.small),
                                                 _ptr(self.basis), _ptr(self.mean), _stream_ptr()),

@@ -590,11 +590,15 @@ def test_gather_mode_bit_identical(sq, orc, N, fp16, density):
 
 
 @pytest.mark.parametrize("N,fp16,density,unit_rows", [(8, True, 0.94, 1024), (8, True, 0.2, 1024), (5, False, 0.6, 0),
-                                                      (16, True, 0.9, 2048), (12, True, 0.5, 0), (3, True, 0.97, 256)])
+                                                      (16, True, 0.9, 2048), (12, True, 0.5, 0), (3, True, 0.97, 256),
+                                                      (20, True, 0.9, 1024), (32, True, 0.8, 0), (24, False, 0.6, 2048),
+                                                      (17, True, 0.95, 0), (28, True, 0.3, 512)])
 def test_walk_mode_bit_identical(sq, orc, N, fp16, density, unit_rows):
     """svdq_compress_masked (source rows walked with the mask byte beside them, selected rows compacted in LDS; no
     index lists, no compacted copies) produces exactly the artifacts of svdq_compress on the compacted tensors --
-    signal region and, with the inverted polarity, noise region alike; unit starts point at the right elements."""
+    signal region and, with the inverted polarity, noise region alike; unit starts point at the right elements.
+    Above 16 tasks the walk runs the one-wave pass 2 (svdq_project_walk.hip) against the two-wave kernels of the
+    compacted run: same association of every sum, so still the same bits."""
     from svdq_amd.pipeline import CompressPlan
     from svdq_amd.mask_loader import MaskSet
     dev = torch.device("cuda", 0)
@@ -617,7 +621,9 @@ def test_walk_mode_bit_identical(sq, orc, N, fp16, density, unit_rows):
     assert torch.equal(ct, ct2) and torch.equal(cf, cf2)
     mtab = torch.tensor([m.data_ptr() for m in ms._s["mb"]], dtype=torch.int64).to(dev)
     for compacted, cnt, inv in ((dt, ct, False), (df, cf, True)):
-        ref = CompressPlan(sizes, N, **kw)
+        # N = 17..20: the default pass 2 takes columns 16..19 through 4x4-block MFMAs (k_basis_project_q), which associate
+        # the task sum differently; plan flag 8 = the two-wave kernel, whose sums the one-wave kernel repeats
+        ref = CompressPlan(sizes, N, flags=8 if 16 < N <= 20 else 0, **kw)
         ref.run(ref.pointer_table(compacted), cnt)
         wlk = CompressPlan(sizes, N, **kw)
         us = ms.unit_starts(wlk, cnt, entry_map=[(q, inv) for q in range(len(sizes))] if inv else None)
@@ -682,8 +688,10 @@ def test_walk_mode_from_checkpoints_and_limits(sq, orc):
     _same_bases(a, b, len(sizes))
     big = CompressPlan(sizes, 20, **kw)
     v20 = [[vecs[p][t % N] for t in range(20)] for p in range(len(sizes))]
-    with pytest.raises(RuntimeError, match="N <= 16"):
-        big.run_masked(big.pointer_table(v20), mtab, ms.unit_starts(big, ct), ct)
+    big.run_masked(big.pointer_table(v20), mtab, ms.unit_starts(big, ct), ct)      # above 16 tasks: the one-wave kernels
+    ft20 = [[base[p] + v20[p][t] for t in range(20)] for p in range(len(sizes))]
+    with pytest.raises(RuntimeError, match="N <= 16"):                                # ... but not straight from checkpoints
+        big.run_masked_from_base(big.pointer_table(ft20), btab, mtab, ms.unit_starts(big, ct), ct)
     other = CompressPlan([s + 1 for s in sizes], N, **kw)
     with pytest.raises(ValueError, match="Shape mismatch"):
         ms.unit_starts(other, ct)
