@@ -282,9 +282,24 @@ def modes_case(sq, dev, seed: int, c: int):
         p_, t_, j_ = [int(v[0]) for v in np.nonzero(~ok)]
         msgs.append(f"diagnostics_masked: parameter {p_} task {t_} field {j_}: {dm[p_, t_, j_]} vs {dc[p_, t_, j_]}")
     extra = []
+    mtab = torch.tensor([x.data_ptr() for x in ms._i["mb"]], dtype=torch.int64).to(dev)
+    if N > 16:
+        # the mask walk above 16 tasks (one-wave kernels) against the compacted run on the two-wave kernels: N = 17..20
+        # default to the 4x4-block pass 2, whose task sums associate differently -- plan flag 8 selects the two-wave one
+        rw = r3
+        if N <= 20:
+            rw = CompressPlan(sizes, N, flags=8, **kw)
+            rw.run(rw.pointer_table(dt), ct)
+            extra.append(rw)
+        wk = CompressPlan(sizes, N, **kw)
+        wk.run_masked(wk.pointer_table(deltas), mtab, ms.unit_starts(wk, ct2, mask_table=mtab), ct2)
+        torch.cuda.synchronize()
+        m = _same(rw, wk)
+        if m:
+            msgs.append("walk (one-wave kernels): " + m)
+        extra.append(wk)
     if N <= 16:
         # the mask walk (no index lists): against the compacted run, and straight from checkpoints against ingest + walk
-        mtab = torch.tensor([x.data_ptr() for x in ms._i["mb"]], dtype=torch.int64).to(dev)
         wk = CompressPlan(sizes, N, **kw)
         us = ms.unit_starts(wk, ct2, mask_table=mtab)
         wk.run_masked(wk.pointer_table(deltas), mtab, us, ct2)
@@ -301,7 +316,7 @@ def modes_case(sq, dev, seed: int, c: int):
         m = _same(w4, wb)
         if m:
             msgs.append("walk_from_base: " + m)
-        extra = [wk, w4, wb]
+        extra += [wk, w4, wb]
     for pl in [r2, fb, r3, ga, r4, gb] + extra:
         pl.close()
     return desc, msgs
