@@ -258,3 +258,27 @@ def test_bench_one_rank_world_over_rccl():
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert len(d["per_rank"]["ranks"]) == 1 and d["per_rank"]["ranks"][0]["tensors"] == 152
     assert d["basis_gather"] is not None and d["basis_gather"]["ms"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_shard_of_is_rank_zeros_lpt_share():
+    """bench.py --shard-of K on one GPU compresses exactly rank 0's LPT share of a K-rank strong-scaling run (the
+    rehearsal DESIGN.md section 6 quotes for what one GPU of the 8-GPU run does per step)."""
+    import json
+    import subprocess
+    import sys
+    from svdq_amd import workloads, shard
+    shapes = workloads.vit_visual_shapes("ViT-B-32")
+    rows = [workloads.numel(shapes[n]) for n in sorted(shapes)]
+    mine = shard.partition_lpt(rows, 8)[0]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SVDQ_DIST_SINGLE", "SVDQ_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "ViT-B-32", "--shard-of", "8", "--steps", "2",
+                        "--warmup", "1", "--no-cpu", "--placement-candidates", "1"], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["tensors_rank0"] == len(mine)
+    assert f"sum D = {sum(rows[i] for i in mine)} " in d["config"]["workload"]
+    assert "share of 8 ranks" in d["config"]["sharding"]
