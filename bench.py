@@ -108,6 +108,7 @@ def parse():
     ap.add_argument("--shard-of", type=int, default=0,
                     help="one GPU: compress only rank 0's share of a strong-scaling run over this many ranks (what one "
                          "GPU of the multi-GPU run does per step; with SVDQ_DIST_SINGLE=1 including the RCCL exchange)")
+    ap.add_argument("--shard-rank", type=int, default=0, help="--shard-of: which rank's share (default 0)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -692,7 +693,7 @@ def main():
     if args.shard_of > 1:
         if world > 1:
             sys.exit("bench.py --shard-of: a one-GPU rehearsal of one rank's share")
-        mine = shard.partition_lpt(rows_all, args.shard_of)[0]
+        mine = shard.partition_lpt(rows_all, args.shard_of)[args.shard_rank % args.shard_of]
     rows = [rows_all[i] for i in mine]
 
     wl = Workload(args, rows, dev, 1234 + rank, world, on_cpu)
@@ -814,7 +815,7 @@ def main():
                                             (f" (tune_placement failed: {placement_error})"
                                              if placement_error else "")),
                        "masks": args.masks, "mask_density": mask_density,
-                       "sharding": (f"rehearsal: rank 0's LPT share of {args.shard_of} ranks" if args.shard_of > 1 else "none")
+                       "sharding": (f"rehearsal: rank {args.shard_rank % args.shard_of}'s LPT share of {args.shard_of} ranks" if args.shard_of > 1 else "none")
                        if world == 1 else (
                            "one model per rank" if scaling == "weak" else "one model, LPT over parameter tensors")},
             "roofline": {"bound": "hbm", "kernel": "k_basis_project", "achieved": round(bp_gbs, 1),
